@@ -1,0 +1,361 @@
+"""Host-side mirror of the reference's join interface on top of libgcre_hip.so (ctypes).
+
+``JoinExec`` / ``PathSet`` follow the reference classes of the same name (src/gcre.h:103-180,
+src/gcre_paths.h:10-98); ``process_paths`` follows ``ProcessPaths`` (src/wrapper.cpp:177-281).  All
+compute happens in the HIP library; there is no CPU path here -- if the library or a gfx950 device is
+missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import build as _build
+
+_LIB = None
+
+GCRE_OK, GCRE_ERR_ASSERT, GCRE_ERR_RANGE, GCRE_ERR_DEVICE, GCRE_ERR_ARG = 0, -1, -2, -3, -4
+
+
+class GcreError(RuntimeError):
+    pass
+
+
+class gcre_result(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("scores", ctypes.POINTER(ctypes.c_double)),
+                ("src", ctypes.POINTER(ctypes.c_int32)), ("trg", ctypes.POINTER(ctypes.c_int32)),
+                ("cases", ctypes.POINTER(ctypes.c_int32)), ("ctrls", ctypes.POINTER(ctypes.c_int32)),
+                ("n_perm", ctypes.c_int32), ("null_max", ctypes.POINTER(ctypes.c_float))]
+
+
+class gcre_join_opts(ctypes.Structure):
+    _fields_ = [("shard_begin", ctypes.c_int64), ("shard_end", ctypes.c_int64), ("d_null_out", ctypes.c_void_p)]
+
+
+class gcre_profile(ctypes.Structure):
+    _fields_ = [("null_kernel_ms", ctypes.c_double), ("null_kernel_launches", ctypes.c_int64),
+                ("stats_kernel_ms", ctypes.c_double), ("select_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
+                ("paths", ctypes.c_int64), ("scores", ctypes.c_int64), ("null_alg_bytes", ctypes.c_double)]
+
+
+class gcre_level(ctypes.Structure):
+    _fields_ = [("uid_count", ctypes.c_void_p), ("uid_location", ctypes.c_void_p), ("n_uids", ctypes.c_int64),
+                ("signs", ctypes.c_void_p), ("n_signs", ctypes.c_int64)]
+
+
+class gcre_pp_input(ctypes.Structure):
+    _fields_ = [("level", gcre_level * 6), ("data_inds", ctypes.c_void_p * 4), ("n_data_inds", ctypes.c_int64 * 4),
+                ("data1", ctypes.c_void_p), ("data1_rows", ctypes.c_int64),
+                ("data2", ctypes.c_void_p), ("data2_rows", ctypes.c_int64), ("data_col_major", ctypes.c_int),
+                ("value_table", ctypes.c_void_p), ("vt_rows", ctypes.c_int), ("vt_cols", ctypes.c_int),
+                ("vt_col_major", ctypes.c_int),
+                ("perm_cases", ctypes.c_void_p), ("perm_rows", ctypes.c_int), ("perm_col_major", ctypes.c_int),
+                ("path_length", ctypes.c_int)]
+
+
+# every symbol include/gcre_hip.h declares; tests check that the library exports all of them
+EXPORTS = [
+    "gcre_create", "gcre_destroy", "gcre_last_error", "gcre_abi_version", "gcre_set_top_k", "gcre_width_ul",
+    "gcre_vlen", "gcre_set_value_table", "gcre_set_perm_cases", "gcre_set_perm_masks", "gcre_pathset_zeros",
+    "gcre_pathset_from_dense", "gcre_pathset_from_words", "gcre_pathset_select", "gcre_pathset_size",
+    "gcre_pathset_read", "gcre_pathset_free", "gcre_join", "gcre_result_free", "gcre_get_profile",
+    "gcre_process_paths", "gcre_resolve_count_locs",
+]
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load_library():
+    """dlopen libgcre_hip.so (building it first if the tree is newer).  Fails loudly when it cannot."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.build()
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:   # no silent fallback: the product IS this library
+        raise GcreError(f"cannot load {path}: {e}") from e
+    V, I, I64, P = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+    lib.gcre_create.restype = V
+    lib.gcre_create.argtypes = [I, I, I, I, I]
+    lib.gcre_destroy.argtypes = [V]
+    lib.gcre_destroy.restype = None
+    lib.gcre_last_error.restype = ctypes.c_char_p
+    lib.gcre_last_error.argtypes = [V]
+    lib.gcre_abi_version.restype = I
+    lib.gcre_set_top_k.argtypes = [V, I]
+    lib.gcre_width_ul.argtypes = [V]
+    lib.gcre_vlen.argtypes = [V]
+    lib.gcre_set_value_table.argtypes = [V, P, I, I, I]
+    lib.gcre_set_perm_cases.argtypes = [V, P, I, I, I]
+    lib.gcre_set_perm_masks.argtypes = [V, P, I]
+    lib.gcre_pathset_zeros.restype = V
+    lib.gcre_pathset_zeros.argtypes = [V, I64]
+    lib.gcre_pathset_from_dense.restype = V
+    lib.gcre_pathset_from_dense.argtypes = [V, P, I64, I, I]
+    lib.gcre_pathset_from_words.restype = V
+    lib.gcre_pathset_from_words.argtypes = [V, P, I64]
+    lib.gcre_pathset_select.restype = V
+    lib.gcre_pathset_select.argtypes = [V, V, P, I64]
+    lib.gcre_pathset_size.restype = I64
+    lib.gcre_pathset_size.argtypes = [V]
+    lib.gcre_pathset_read.argtypes = [V, V, P]
+    lib.gcre_pathset_free.argtypes = [V]
+    lib.gcre_pathset_free.restype = None
+    lib.gcre_join.argtypes = [V, I, P, P, I64, P, I64, V, V, V, ctypes.POINTER(gcre_join_opts),
+                              ctypes.POINTER(gcre_result)]
+    lib.gcre_result_free.argtypes = [ctypes.POINTER(gcre_result)]
+    lib.gcre_result_free.restype = None
+    lib.gcre_get_profile.argtypes = [V, ctypes.POINTER(gcre_profile)]
+    lib.gcre_process_paths.argtypes = [V, ctypes.POINTER(gcre_pp_input), ctypes.POINTER(gcre_result)]
+    lib.gcre_resolve_count_locs.argtypes = [P, I64, P, P, P, I64, P, P]
+    _LIB = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+@dataclass
+class JoinResult:
+    """joined_res (src/gcre_types.h:45-48) as arrays; what make_score_list turns into an R list (wrapper.cpp:142-174)."""
+
+    scores: np.ndarray     # float64 ascending
+    src: np.ndarray        # idx; R sees ids[,1] = src + 1
+    trg: np.ndarray        # loc; R sees ids[,2] = trg + 1
+    cases: np.ndarray
+    ctrls: np.ndarray
+    null: np.ndarray       # float32 [iterations] -- "TestScores"
+
+    def pvalues(self) -> np.ndarray:
+        """#(TestScores >= score) / length(TestScores), R/ProcessPaths.R:316 (f64 score vs f32 maxima)."""
+        t = self.null.astype(np.float64)
+        if len(t) == 0:
+            return np.full(len(self.scores), np.nan)
+        return np.array([(t >= s).sum() / len(t) for s in self.scores])
+
+    def as_r_list(self) -> Dict[str, object]:
+        """The named list make_score_list builds (wrapper.cpp:167-173)."""
+        return {
+            "scores": self.scores,
+            "ids": np.stack([self.src + 1, self.trg + 1], axis=1) if len(self.src) else np.zeros((0, 2), np.int32),
+            "TestScores": self.null.astype(np.float64),
+            "cases": self.cases.astype(np.float64),
+            "controls": self.ctrls.astype(np.float64),
+            "debug": [f"[debug] {s}:{t} {c}/{d}" for s, t, c, d in
+                      zip(self.src.tolist(), self.trg.tolist(), self.cases.tolist(), self.ctrls.tolist())],
+        }
+
+
+def _take_result(lib, r: gcre_result) -> JoinResult:
+    n, k = r.n, r.n_perm
+    out = JoinResult(
+        np.ctypeslib.as_array(r.scores, (n,)).copy() if n > 0 else np.zeros(0),
+        np.ctypeslib.as_array(r.src, (n,)).copy() if n > 0 else np.zeros(0, np.int32),
+        np.ctypeslib.as_array(r.trg, (n,)).copy() if n > 0 else np.zeros(0, np.int32),
+        np.ctypeslib.as_array(r.cases, (n,)).copy() if n > 0 else np.zeros(0, np.int32),
+        np.ctypeslib.as_array(r.ctrls, (n,)).copy() if n > 0 else np.zeros(0, np.int32),
+        np.ctypeslib.as_array(r.null_max, (k,)).copy() if k > 0 else np.zeros(0, np.float32),
+    )
+    lib.gcre_result_free(ctypes.byref(r))
+    return out
+
+
+class PathSet:
+    """Device-resident PathSet (src/gcre_paths.h:10-98)."""
+
+    def __init__(self, owner: "JoinExec", handle: int):
+        if not handle:
+            owner._raise()
+        self._owner, self._h = owner, handle
+        self.size = int(owner._lib.gcre_pathset_size(handle))
+        self.vlen = owner.vlen
+
+    def select(self, indices) -> "PathSet":
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        return PathSet(self._owner, self._owner._lib.gcre_pathset_select(self._owner._h, self._h, _ptr(idx), len(idx)))
+
+    def to_numpy(self) -> np.ndarray:
+        out = np.zeros((self.size, self.vlen), dtype=np.uint64)
+        self._owner._check(self._owner._lib.gcre_pathset_read(self._owner._h, self._h, _ptr(out)))
+        return out
+
+    def free(self) -> None:
+        h, self._h = self._h, None
+        if h and self._owner._h:
+            self._owner._lib.gcre_pathset_free(h)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class JoinExec:
+    """JoinExec (src/gcre.h:103-180) on one MI355X.  ``method`` is "method1" | "method2" or 1 | 2."""
+
+    def __init__(self, method, num_cases: int, num_ctrls: int, iters: int, device: int = 0):
+        self._lib = load_library()
+        if isinstance(method, str):
+            method = 1 if method == "method1" else 2   # JoinExec::to_method, gcre.h:125-133
+        self.method, self.num_cases, self.num_ctrls, self.iters = int(method), int(num_cases), int(num_ctrls), int(iters)
+        self._h = self._lib.gcre_create(self.method, self.num_cases, self.num_ctrls, self.iters, int(device))
+        if not self._h:
+            msg = self._lib.gcre_last_error(None).decode()
+            if msg.startswith("assertion"):
+                raise ValueError(msg)
+            raise GcreError(msg)
+        self.width_ul = self._lib.gcre_width_ul(self._h)
+        self.vlen = self._lib.gcre_vlen(self._h)
+        self._top_k = 12
+        self.nthreads = 0   # accepted for interface parity; the device schedules the work
+
+    # -- plumbing --
+    def _raise(self, rc: int = GCRE_ERR_DEVICE):
+        msg = self._lib.gcre_last_error(self._h).decode()
+        if rc == GCRE_ERR_RANGE or "out of range" in msg:
+            raise IndexError(msg)          # std::out_of_range
+        if rc == GCRE_ERR_ASSERT or msg.startswith("assertion"):
+            raise ValueError(msg)          # std::logic_error
+        raise GcreError(msg)
+
+    def _check(self, rc: int):
+        if rc != GCRE_OK:
+            self._raise(rc)
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            self._lib.gcre_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def top_k(self) -> int:
+        return self._top_k
+
+    @top_k.setter
+    def top_k(self, k: int):
+        self._check(self._lib.gcre_set_top_k(self._h, int(k)))
+        self._top_k = int(k)
+
+    # -- JoinExec interface --
+    def set_value_table(self, table) -> None:
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        self._check(self._lib.gcre_set_value_table(self._h, _ptr(t), t.shape[0], t.shape[1], 0))
+
+    def set_permuted_cases(self, perms) -> None:
+        p = np.ascontiguousarray(perms, dtype=np.int32)
+        if p.ndim != 2:
+            p = p.reshape(0, 0)
+        self._check(self._lib.gcre_set_perm_cases(self._h, _ptr(p), p.shape[0], p.shape[1], 0))
+
+    def set_permuted_masks(self, masks) -> None:
+        m = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, self.width_ul)
+        self._check(self._lib.gcre_set_perm_masks(self._h, _ptr(m), m.shape[0]))
+
+    def create_path_set(self, size: int) -> PathSet:
+        return PathSet(self, self._lib.gcre_pathset_zeros(self._h, int(size)))
+
+    def load(self, data) -> PathSet:
+        d = np.ascontiguousarray(data, dtype=np.int32)
+        ncol = d.shape[1] if d.ndim == 2 else 0
+        return PathSet(self, self._lib.gcre_pathset_from_dense(self._h, _ptr(d), d.shape[0], ncol, 0))
+
+    def from_words(self, rows) -> PathSet:
+        r = np.ascontiguousarray(rows, dtype=np.uint64).reshape(-1, self.vlen)
+        return PathSet(self, self._lib.gcre_pathset_from_words(self._h, _ptr(r), r.shape[0]))
+
+    def join(self, uids, paths0: PathSet, paths1: PathSet, paths_res: Optional[PathSet] = None,
+             shard: Optional[Tuple[int, int]] = None, d_null_out: int = 0) -> JoinResult:
+        """JoinExec::join (src/join_base.cpp:189-264).  ``paths_res`` receives the joined rows when given."""
+        count = np.ascontiguousarray(uids.count, dtype=np.int32)
+        location = np.ascontiguousarray(uids.location, dtype=np.int64)
+        signs = np.ascontiguousarray(uids.signs, dtype=np.int32)
+        opts = gcre_join_opts(0, 0, None)
+        if shard is not None:
+            opts.shard_begin, opts.shard_end = int(shard[0]), int(shard[1])
+        if d_null_out:
+            opts.d_null_out = ctypes.c_void_p(int(d_null_out))
+        res = gcre_result()
+        rc = self._lib.gcre_join(self._h, int(uids.path_length), _ptr(count), _ptr(location), len(count),
+                                 _ptr(signs), len(signs), paths0._h, paths1._h,
+                                 paths_res._h if paths_res is not None else None, ctypes.byref(opts), ctypes.byref(res))
+        self._check(rc)
+        return _take_result(self._lib, res)
+
+    def profile(self) -> Dict[str, float]:
+        p = gcre_profile()
+        self._check(self._lib.gcre_get_profile(self._h, ctypes.byref(p)))
+        return {f: getattr(p, f) for f, _ in gcre_profile._fields_}
+
+
+def resolve_count_locs(trg_uids, keys, counts, locations):
+    """assemble_uids' lookup (src/wrapper.cpp:106-132) through the C ABI."""
+    lib = load_library()
+    trg = np.ascontiguousarray(trg_uids, dtype=np.int32)
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    locations = np.ascontiguousarray(locations, dtype=np.int32)
+    oc = np.zeros(len(trg), dtype=np.int32)
+    ol = np.zeros(len(trg), dtype=np.int64)
+    rc = lib.gcre_resolve_count_locs(_ptr(trg), len(trg), _ptr(keys), _ptr(counts), _ptr(locations), len(keys),
+                                     _ptr(oc), _ptr(ol))
+    if rc != GCRE_OK:
+        raise GcreError(f"gcre_resolve_count_locs failed: {rc}")
+    return oc, ol
+
+
+def process_paths(problem, device: int = 0, exec_: Optional[JoinExec] = None) -> Dict[str, object]:
+    """ProcessPaths (src/wrapper.cpp:177-281) in one native call.  Returns {"lst1": JoinResult | None, ...}.
+
+    ``problem`` carries the 39 arguments as arrays (geneticscre_amd.synth.Problem).
+    """
+    ex = exec_ or JoinExec(problem.method, problem.n_cases, problem.n_ctrls, problem.iterations, device)
+    ex.top_k = problem.top_k
+    lib = ex._lib
+    keep = []   # keep numpy buffers alive across the call
+
+    def arr(a, dt):
+        b = np.ascontiguousarray(a, dtype=dt)
+        keep.append(b)
+        return b
+
+    inp = gcre_pp_input()
+    for i, name in enumerate(["1a", "1b", "2", "3", "4", "5"]):
+        u = problem.levels.uids[name]
+        c, l, s = arr(u.count, np.int32), arr(u.location, np.int64), arr(u.signs, np.int32)
+        inp.level[i] = gcre_level(_ptr(c), _ptr(l), len(c), _ptr(s), len(s))
+    for i, name in enumerate(["1a", "1b", "2", "3"]):
+        d = arr(problem.levels.data_inds[name], np.int32)
+        inp.data_inds[i], inp.n_data_inds[i] = _ptr(d), len(d)
+    d1, d2 = arr(problem.data1, np.int32), arr(problem.data2, np.int32)
+    inp.data1, inp.data1_rows, inp.data2, inp.data2_rows, inp.data_col_major = _ptr(d1), d1.shape[0], _ptr(d2), d2.shape[0], 0
+    vt = arr(problem.value_table, np.float64)
+    inp.value_table, inp.vt_rows, inp.vt_cols, inp.vt_col_major = _ptr(vt), vt.shape[0], vt.shape[1], 0
+    pc = arr(problem.perm_cases, np.int32)
+    inp.perm_cases = _ptr(pc) if pc.size else None
+    inp.perm_rows, inp.perm_col_major = (pc.shape[0] if pc.ndim == 2 else 0), 0
+    inp.path_length = int(problem.path_length)
+    outs = (gcre_result * 5)()
+    rc = lib.gcre_process_paths(ex._h, ctypes.byref(inp), outs)
+    ex._check(rc)
+    result: Dict[str, object] = {}
+    for i in range(5):
+        result[f"lst{i + 1}"] = None if outs[i].n < 0 else _take_result(lib, outs[i])
+    result["profile"] = ex.profile()
+    if exec_ is None:
+        ex.close()
+    return result

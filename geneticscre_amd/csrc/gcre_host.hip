@@ -1,0 +1,961 @@
+// gcre_host.hip -- host side of libgcre_hip.so: the C ABI of include/gcre_hip.h on top of the gfx950
+// kernels in gcre_kernels.hip.  Owns device memory, the stream, the join driver (JoinExec::join,
+// reference src/join_base.cpp:189-264), the top-k merge (merge_scores / format_result, methods.h:25-39,
+// join_base.cpp:138-154) and the ProcessPaths sequence (src/wrapper.cpp:216-276).
+//
+// There is no CPU fallback: without a gfx950 device gcre_create fails with GCRE_ERR_DEVICE.
+#include "../../include/gcre_hip.h"
+#include "gcre_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace gcre;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {   // grow-only device scratch
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct Candidate {
+  double score;
+  int64_t path;   // absolute joined-path ordinal
+  int32_t src, trg, cases, ctrls;
+};
+
+inline double key_to_score(uint64_t k) {
+  const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  double d;
+  std::memcpy(&d, &b, sizeof d);
+  return d;
+}
+
+inline size_t tri(size_t t) { return t * (t + 1) / 2; }
+
+}  // namespace
+
+struct gcre_ctx {
+  Geometry g{};
+  int device = 0;
+  int top_k = 12;   // JoinExec::top_k, gcre.h:120
+  hipStream_t stream = nullptr;
+  std::string err;
+  int last_code = GCRE_OK;
+  bool quiet = false;
+  bool have_table = false, have_perms = false;
+  int64_t chunk_paths = int64_t(1) << 25;
+  int null_blocks_per_cu = 12;
+
+  // resident inputs
+  uint64_t* d_case_mask = nullptr;   // [Wp]
+  uint32_t* d_masks = nullptr;       // [W32p][Kpad]
+  float* d_t32 = nullptr;            // method 1 null table
+  double* d_dvt = nullptr;           // observed-score table
+  double* d_dmax = nullptr;          // method 2 null table (vtmax)
+  uint32_t* d_null = nullptr;        // [Kpad]
+
+  // per-join scratch
+  DevBuf<int64_t> d_path_idx, d_location;
+  DevBuf<int32_t> d_signs;
+  DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
+  DevBuf<uint64_t> d_key, d_wkey;
+  DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
+
+  gcre_profile prof{};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_null, ev_stats;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+struct gcre_pathset {
+  gcre_ctx* ctx;
+  int64_t nrows;
+  uint64_t* d_rows;   // max(nrows,1) x S words
+};
+
+namespace {
+
+int fail(gcre_ctx* c, int code, const std::string& msg) {
+  if (c) {
+    c->err = msg;
+    c->last_code = code;
+  } else {
+    g_create_error = msg;
+  }
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                            \
+  do {                                                                                                \
+    hipError_t e__ = (expr);                                                                          \
+    if (e__ != hipSuccess)                                                                            \
+      return fail((ctx), GCRE_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+  } while (0)
+
+hipEvent_t get_event(gcre_ctx* c) {
+  if (!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+double drain_events(gcre_ctx* c, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+  double ms = 0;
+  for (auto& pr : v) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) ms += t;
+    c->ev_pool.push_back(pr.first);
+    c->ev_pool.push_back(pr.second);
+  }
+  v.clear();
+  return ms;
+}
+
+gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
+  if (nrows < 0) {
+    fail(c, GCRE_ERR_ARG, "negative path-set size");
+    return nullptr;
+  }
+  // rows are addressed by 31-bit row numbers and 32-bit offsets in 32-byte units inside the null kernel
+  const int64_t units = nrows * (int64_t)(c->g.S / 4);
+  if (nrows >= (int64_t(1) << 31) || units >= (int64_t(1) << 32)) {
+    fail(c, GCRE_ERR_RANGE, "path set too large for 32-bit row addressing");
+    return nullptr;
+  }
+  auto* ps = new gcre_pathset{c, nrows, nullptr};
+  const size_t bytes = (size_t)std::max<int64_t>(nrows, 1) * c->g.S * sizeof(uint64_t);
+  if (hipMalloc((void**)&ps->d_rows, bytes) != hipSuccess) {
+    fail(c, GCRE_ERR_DEVICE, "hipMalloc failed for a path set of " + std::to_string(bytes) + " bytes");
+    delete ps;
+    return nullptr;
+  }
+  if (zero || nrows == 0) {
+    if (hipMemsetAsync(ps->d_rows, 0, bytes, c->stream) != hipSuccess) {
+      fail(c, GCRE_ERR_DEVICE, "hipMemsetAsync failed");
+      (void)hipFree(ps->d_rows);
+      delete ps;
+      return nullptr;
+    }
+  }
+  return ps;
+}
+
+// ---- top-k selection of one scored chunk: indices of the best min(k, valid) keys, ties cut in index order ----
+int select_chunk(gcre_ctx* c, int64_t count, int k, uint32_t* n_selected) {
+  *n_selected = 0;
+  if (count == 0 || k <= 0) return GCRE_OK;
+  HIP_TRY(c, c->d_small.reserve(512));
+  HIP_TRY(c, c->d_sel.reserve((size_t)k + 64));
+  uint32_t* d_hist = c->d_small.p;
+  uint32_t* d_counter = c->d_small.p + 256;
+  const uint64_t* key = c->d_key.p;
+
+  uint64_t prefix = 0;
+  int64_t need = std::min<int64_t>(k, count);
+  int64_t greater = 0;
+  uint32_t eq_count = 0;
+  uint32_t h[256];
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    HIP_TRY(c, hipMemsetAsync(d_hist, 0, 256 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, launch_hist(key, count, shift, prefix, d_hist, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h, d_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int64_t cum = 0;
+    int b = 255;
+    for (; b > 0; b--) {
+      if (cum + h[b] >= need) break;
+      cum += h[b];
+    }
+    greater += cum;
+    need -= cum;
+    eq_count = h[b];
+    prefix = (prefix << 8) | (uint64_t)b;
+  }
+  const uint64_t T = prefix;   // the need-th largest key overall
+  HIP_TRY(c, hipMemsetAsync(d_counter, 0, sizeof(uint32_t), c->stream));
+  uint32_t nsel = 0;
+  if (T == 0) {
+    // fewer scorable paths than k: everything with a real score is selected
+    HIP_TRY(c, launch_collect_gt(key, count, 0, c->d_sel.p, d_counter, (uint32_t)k, c->stream));
+    nsel = (uint32_t)greater;
+  } else if ((int64_t)eq_count == need) {
+    // every path that ties with the threshold is wanted: no cut needed
+    HIP_TRY(c, launch_collect_gt(key, count, T - 1, c->d_sel.p, d_counter, (uint32_t)k, c->stream));
+    nsel = (uint32_t)(greater + need);
+  } else {
+    // ties at the threshold exceed the remaining slots: keep the `need` smallest ordinals
+    HIP_TRY(c, launch_collect_gt(key, count, T, c->d_sel.p, d_counter, (uint32_t)k, c->stream));
+    const int64_t chunks = (count + 1023) / 1024;
+    HIP_TRY(c, c->d_chunk.reserve((size_t)chunks));
+    HIP_TRY(c, launch_eq_count(key, count, T, c->d_chunk.p, c->stream));
+    std::vector<uint32_t> cnt((size_t)chunks);
+    HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_chunk.p, cnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t run = 0;
+    for (auto& v : cnt) {
+      const uint32_t t = v;
+      v = run;
+      run += t;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_chunk.p, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, launch_eq_collect(key, count, T, c->d_chunk.p, (uint32_t)need, c->d_sel.p + greater, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // cnt must outlive the copy
+    nsel = (uint32_t)(greater + need);
+  }
+  *n_selected = nsel;
+  return GCRE_OK;
+}
+
+struct JoinPlan {
+  int path_length;
+  const int32_t* uid_count;
+  const int64_t* uid_location;
+  int64_t n_uids;
+  const int32_t* signs;
+  int64_t n_signs;
+  const gcre_pathset* p0;
+  const gcre_pathset* p1;
+  gcre_pathset* res;
+  int64_t shard_begin, shard_end;
+  void* d_null_out;
+};
+
+int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
+  const Geometry& g = c->g;
+  const auto t_begin = std::chrono::steady_clock::now();
+  std::memset(out, 0, sizeof *out);
+  if (!c->have_table) return fail(c, GCRE_ERR_ASSERT, "value table not set");
+  if (g.K > 0 && !c->have_perms) return fail(c, GCRE_ERR_ASSERT, "permuted cases not set");
+  if (c->top_k < 1) return fail(c, GCRE_ERR_ARG, "top_k must be >= 1");
+  if (!jp.p0 || !jp.p1 || jp.p0->ctx != c || jp.p1->ctx != c || (jp.res && jp.res->ctx != c))
+    return fail(c, GCRE_ERR_ARG, "path set does not belong to this context");
+
+  // ---- the checks of JoinExec::join, join_base.cpp:196-200 ----
+  if (jp.n_uids != jp.p0->nrows) return fail(c, GCRE_ERR_ASSERT, "assertion: uids.size() != paths0.size");
+  std::vector<int64_t> path_idx((size_t)jp.n_uids + 1, 0);
+  int64_t max_loc = -1, max_idx = -1;
+  for (int64_t i = 0; i < jp.n_uids; i++) {
+    const int cnt = jp.uid_count[i];
+    if (cnt > 0) {
+      const int64_t loc = jp.uid_location[i];
+      if (loc < 0 || loc + cnt - 1 >= jp.p1->nrows) return fail(c, GCRE_ERR_RANGE, "assertion: uid location out of range");
+      max_loc = std::max(max_loc, loc + cnt - 1);
+      max_idx = i;
+    }
+    path_idx[(size_t)i + 1] = path_idx[(size_t)i] + std::max(cnt, 0);   // uid_ref.path_idx, wrapper.cpp:128-130
+  }
+  const int64_t P = path_idx[(size_t)jp.n_uids];
+  const bool keep = jp.res != nullptr && jp.res->nrows != 0;   // keep_paths = paths_res.size != 0, join_base.cpp:217
+  if (jp.res && jp.res->nrows != 0 && jp.res->nrows != P)
+    return fail(c, GCRE_ERR_ASSERT, "assertion: paths_res.size != total paths");
+  if (g.method == 2 && P > 0) {
+    // need_flip reads signs[idx] and/or signs[loc] (gcre.h:71-81); the reference would read out of bounds
+    int64_t need_signs = 0;
+    if (jp.path_length > 3) need_signs = max_idx + 1;
+    else if (jp.path_length < 3) need_signs = max_loc + 1;
+    else need_signs = std::max(max_idx, max_loc) + 1;
+    if (jp.n_signs < need_signs) return fail(c, GCRE_ERR_RANGE, "signs vector shorter than the rows it is indexed by");
+  }
+
+  int64_t sb = jp.shard_begin, se = jp.shard_end;
+  if (se <= 0) { sb = 0; se = P; }
+  sb = std::max<int64_t>(0, std::min(sb, P));
+  se = std::max(sb, std::min(se, P));
+
+  hipStream_t st = c->stream;
+  const int Kpad = g.Kpad;
+  if (Kpad > 0) HIP_TRY(c, hipMemsetAsync(c->d_null, 0, (size_t)Kpad * 4, st));
+
+  const NullConfig cfg = null_config(g.method, g.K);
+  std::vector<Candidate> cands;
+  c->prof = gcre_profile{};
+  double select_ms = 0;
+
+  if (P > 0) {
+    HIP_TRY(c, c->d_path_idx.reserve(path_idx.size()));
+    HIP_TRY(c, c->d_location.reserve((size_t)jp.n_uids));
+    HIP_TRY(c, hipMemcpyAsync(c->d_path_idx.p, path_idx.data(), path_idx.size() * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_location.p, jp.uid_location, (size_t)jp.n_uids * 8, hipMemcpyHostToDevice, st));
+    if (g.method == 2) {
+      HIP_TRY(c, c->d_signs.reserve((size_t)std::max<int64_t>(jp.n_signs, 1)));
+      if (jp.n_signs > 0)
+        HIP_TRY(c, hipMemcpyAsync(c->d_signs.p, jp.signs, (size_t)jp.n_signs * 4, hipMemcpyHostToDevice, st));
+    }
+
+    // segments: rows outside the shard are only materialised (when kept); the shard is scored
+    struct Seg { int64_t b, e; bool score; };
+    std::vector<Seg> segs;
+    if (keep && sb > 0) segs.push_back({0, sb, false});
+    if (se > sb) segs.push_back({sb, se, true});
+    if (keep && se < P) segs.push_back({se, P, false});
+
+    const int64_t tile = cfg.path_tile;
+    const int64_t chunk_cap = std::max<int64_t>(tile, (c->chunk_paths / tile) * tile);
+    const size_t cap = (size_t)std::min<int64_t>(chunk_cap, ((P + tile - 1) / tile) * tile) + (size_t)tile;
+    HIP_TRY(c, c->d_row0.reserve(cap));
+    HIP_TRY(c, c->d_row1.reserve(cap));
+    HIP_TRY(c, c->d_tot.reserve(cap * g.method));
+    HIP_TRY(c, c->d_cases.reserve(cap));
+    HIP_TRY(c, c->d_ctrls.reserve(cap));
+    HIP_TRY(c, c->d_key.reserve(cap));
+
+    for (const Seg& sg : segs) {
+      for (int64_t cb = sg.b; cb < sg.e; cb += chunk_cap) {
+        const int64_t n = std::min(chunk_cap, sg.e - cb);
+        const int64_t npt = (n + tile - 1) / tile;
+        const int64_t padded = npt * tile;
+        // the null kernel reads whole tiles: rows / totals beyond n must be valid (row 0, zero carriers)
+        if (padded > n) {
+          HIP_TRY(c, hipMemsetAsync(c->d_row0.p + n, 0, (size_t)(padded - n) * 4, st));
+          HIP_TRY(c, hipMemsetAsync(c->d_row1.p + n, 0, (size_t)(padded - n) * 4, st));
+          HIP_TRY(c, hipMemsetAsync(c->d_tot.p + (size_t)n * g.method, 0, (size_t)(padded - n) * 4 * g.method, st));
+        }
+        hipEvent_t e0 = get_event(c), e1 = get_event(c);
+        HIP_TRY(c, hipEventRecord(e0, st));
+        HIP_TRY(c, launch_expand(c->d_path_idx.p, c->d_location.p, jp.n_uids, c->d_signs.p, jp.path_length, g.method,
+                                 cb, n, c->d_row0.p, c->d_row1.p, st));
+        StatsArgs sa{};
+        sa.p0 = jp.p0->d_rows;
+        sa.p1 = jp.p1->d_rows;
+        sa.row0 = c->d_row0.p;
+        sa.row1 = c->d_row1.p;
+        sa.case_mask = c->d_case_mask;
+        sa.dvt = c->d_dvt;
+        sa.key = c->d_key.p;
+        sa.tot = c->d_tot.p;
+        sa.cases = c->d_cases.p;
+        sa.ctrls = c->d_ctrls.p;
+        sa.res = keep ? jp.res->d_rows : nullptr;
+        sa.first = cb;
+        sa.count = n;
+        sa.S = g.S;
+        sa.Wp = g.Wp;
+        HIP_TRY(c, launch_stats(sa, g.method, st));
+        HIP_TRY(c, hipEventRecord(e1, st));
+        c->ev_stats.emplace_back(e0, e1);
+        if (!sg.score) continue;
+
+        if (g.K > 0) {
+          NullArgs na{};
+          na.p0 = (const uint32_t*)jp.p0->d_rows;
+          na.p1 = (const uint32_t*)jp.p1->d_rows;
+          na.masks = c->d_masks;
+          na.row0 = c->d_row0.p;
+          na.row1 = c->d_row1.p;
+          na.tot = c->d_tot.p;
+          na.t32 = c->d_t32;
+          na.d64 = c->d_dmax;
+          na.null_bits = c->d_null;
+          na.npaths = n;
+          na.npt = npt;
+          na.S32 = 2 * g.S;
+          na.W32p = 2 * g.Wp;
+          na.Kpad = Kpad;
+          na.nkt = (g.K + cfg.perm_tile - 1) / cfg.perm_tile;
+          int dev_cus = 256;
+          (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+          const int64_t want = (int64_t)dev_cus * c->null_blocks_per_cu;
+          int64_t groups = std::max<int64_t>(1, want / na.nkt);
+          groups = std::min<int64_t>(groups, npt);
+          na.pgroups = (int)groups;
+          hipEvent_t n0 = get_event(c), n1 = get_event(c);
+          HIP_TRY(c, hipEventRecord(n0, st));
+          HIP_TRY(c, launch_null(na, g.method, cfg, st));
+          HIP_TRY(c, hipEventRecord(n1, st));
+          c->ev_null.emplace_back(n0, n1);
+          c->prof.null_kernel_launches++;
+          // algorithmic bytes of this launch (DESIGN.md "Roofline accounting"): both operand rows of every
+          // joined path once, the mask block once, the row/total side arrays, the null maxima
+          c->prof.null_alg_bytes += (double)n * (2.0 * g.S * 8 + 8.0 + 4.0 * g.method) +
+                                    (double)(2 * g.Wp) * g.K * 4.0 + (double)g.K * 4.0;
+        }
+
+        // ---- top-k of this chunk ----
+        const auto ts0 = std::chrono::steady_clock::now();
+        uint32_t nsel = 0;
+        int rc = select_chunk(c, n, c->top_k, &nsel);
+        if (rc != GCRE_OK) return rc;
+        if (nsel > 0) {
+          HIP_TRY(c, c->d_wkey.reserve(nsel));
+          HIP_TRY(c, c->d_wcases.reserve(nsel));
+          HIP_TRY(c, c->d_wctrls.reserve(nsel));
+          HIP_TRY(c, c->d_wrow0.reserve(nsel));
+          HIP_TRY(c, c->d_wrow1.reserve(nsel));
+          HIP_TRY(c, launch_gather_winners(c->d_sel.p, nsel, c->d_key.p, c->d_cases.p, c->d_ctrls.p, c->d_row0.p,
+                                           c->d_row1.p, c->d_wkey.p, c->d_wcases.p, c->d_wctrls.p, c->d_wrow0.p,
+                                           c->d_wrow1.p, st));
+          std::vector<uint32_t> h_sel(nsel), h_cases(nsel), h_ctrls(nsel), h_r0(nsel), h_r1(nsel);
+          std::vector<uint64_t> h_key(nsel);
+          HIP_TRY(c, hipMemcpyAsync(h_sel.data(), c->d_sel.p, nsel * 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(h_key.data(), c->d_wkey.p, nsel * 8, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(h_cases.data(), c->d_wcases.p, nsel * 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(h_ctrls.data(), c->d_wctrls.p, nsel * 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(h_r0.data(), c->d_wrow0.p, nsel * 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(h_r1.data(), c->d_wrow1.p, nsel * 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipStreamSynchronize(st));
+          for (uint32_t i = 0; i < nsel; i++)
+            cands.push_back(Candidate{key_to_score(h_key[i]), cb + (int64_t)h_sel[i], (int32_t)h_r0[i], (int32_t)h_r1[i],
+                                      (int32_t)h_cases[i], (int32_t)h_ctrls[i]});
+        }
+        select_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count();
+        c->prof.paths += n;
+      }
+    }
+  }
+
+  // ---- null maxima: first K entries, f32 (methods.h:101-102; format_result, join_base.cpp:144-146) ----
+  out->n_perm = g.K;
+  out->null_max = (float*)std::calloc((size_t)std::max(g.K, 1), sizeof(float));
+  if (g.K > 0) {
+    HIP_TRY(c, hipMemcpyAsync(out->null_max, c->d_null, (size_t)g.K * 4, hipMemcpyDeviceToHost, st));
+    if (jp.d_null_out) HIP_TRY(c, hipMemcpyAsync(jp.d_null_out, c->d_null, (size_t)g.K * 4, hipMemcpyDeviceToDevice, st));
+  }
+  HIP_TRY(c, hipStreamSynchronize(st));
+
+  // ---- merge: global heap starts with the {-inf,-1,-1,0,0} sentinel (join_base.cpp:192-194); the best
+  // top_k of {sentinel} U candidates survive, reported in ascending order (format_result :140-151).
+  // Ties: smaller joined-path ordinal wins (DESIGN.md "Ties").
+  std::sort(cands.begin(), cands.end(), [](const Candidate& a, const Candidate& b) {
+    if (a.score != b.score) return a.score > b.score;
+    return a.path < b.path;
+  });
+  size_t keepn = std::min(cands.size(), (size_t)c->top_k);
+  const bool with_sentinel = cands.size() < (size_t)c->top_k;
+  const size_t n_out = keepn + (with_sentinel ? 1 : 0);
+  out->n = (int32_t)n_out;
+  out->scores = (double*)std::calloc(std::max<size_t>(n_out, 1), sizeof(double));
+  out->src = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+  out->trg = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+  out->cases = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+  out->ctrls = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+  size_t o = 0;
+  if (with_sentinel) {
+    out->scores[o] = -std::numeric_limits<double>::infinity();
+    out->src[o] = -1;
+    out->trg[o] = -1;
+    o++;
+  }
+  for (size_t i = keepn; i-- > 0;) {   // ascending: worst kept first
+    out->scores[o] = cands[i].score;
+    out->src[o] = cands[i].src;
+    out->trg[o] = cands[i].trg;
+    out->cases[o] = cands[i].cases;
+    out->ctrls[o] = cands[i].ctrls;
+    o++;
+  }
+
+  c->prof.null_kernel_ms = drain_events(c, c->ev_null);
+  c->prof.stats_kernel_ms = drain_events(c, c->ev_stats);
+  c->prof.select_ms = select_ms;
+  c->prof.scores = c->prof.paths * (int64_t)g.K;
+  c->prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return GCRE_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int gcre_abi_version(void) { return GCRE_ABI_VERSION; }
+
+const char* gcre_last_error(const gcre_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int device) {
+  // check_true(num_cases > 0 && num_ctrls > 0 && iters >= 0), join_base.cpp:47
+  if ((method != 1 && method != 2) || n_cases <= 0 || n_ctrls <= 0 || iterations < 0) {
+    g_create_error = "assertion: need method in {1,2}, num_cases > 0, num_ctrls > 0, iterations >= 0";
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device: libgcre_hip has no CPU fallback";
+    return nullptr;
+  }
+  if (device < 0 || device >= ndev) {
+    g_create_error = "device index out of range";
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    g_create_error = "cannot select HIP device";
+    return nullptr;
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName;
+    return nullptr;
+  }
+  auto* c = new gcre_ctx();
+  c->device = device;
+  Geometry& g = c->g;
+  g.method = method;
+  g.n = n_cases + n_ctrls;
+  g.n_cases = n_cases;
+  g.W = (g.n + 63) / 64;
+  g.Wp = ((g.W + 3) / 4) * 4;
+  g.S = g.Wp * method;
+  g.K = iterations;
+  g.Kpad = ((iterations + kPermTileMax - 1) / kPermTileMax) * kPermTileMax;
+  g.TD = 64 * g.Wp + 1;
+  if (const char* e = std::getenv("GCRE_QUIET")) c->quiet = std::atoi(e) != 0;
+  if (const char* e = std::getenv("GCRE_CHUNK_PATHS")) c->chunk_paths = std::max<long long>(64, std::atoll(e));
+  if (const char* e = std::getenv("GCRE_NULL_BLOCKS_PER_CU")) c->null_blocks_per_cu = std::max(1, std::atoi(e));
+
+  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_case_mask, (size_t)g.Wp * 8) == hipSuccess;
+  if (ok && g.Kpad > 0) {
+    ok = hipMalloc((void**)&c->d_masks, (size_t)2 * g.Wp * g.Kpad * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_null, (size_t)g.Kpad * 4) == hipSuccess;
+    ok = ok && hipMemsetAsync(c->d_masks, 0, (size_t)2 * g.Wp * g.Kpad * 4, c->stream) == hipSuccess;
+  }
+  if (ok) {
+    // cases are patient columns 0..n_cases-1, join_base.cpp:50-54
+    std::vector<uint64_t> cm((size_t)g.Wp, 0);
+    for (int k = 0; k < n_cases; k++) cm[(size_t)k / 64] |= uint64_t(1) << (k % 64);
+    ok = hipMemcpy(c->d_case_mask, cm.data(), cm.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (!ok) {
+    g_create_error = "device allocation failed in gcre_create";
+    gcre_destroy(c);
+    return nullptr;
+  }
+  return c;
+}
+
+void gcre_destroy(gcre_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (void* p : {(void*)c->d_case_mask, (void*)c->d_masks, (void*)c->d_t32, (void*)c->d_dvt, (void*)c->d_dmax,
+                  (void*)c->d_null})
+    if (p) (void)hipFree(p);
+  c->d_path_idx.release();
+  c->d_location.release();
+  c->d_signs.release();
+  for (auto* b : {&c->d_row0, &c->d_row1, &c->d_tot, &c->d_cases, &c->d_ctrls, &c->d_sel, &c->d_small, &c->d_chunk,
+                  &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})
+    b->release();
+  c->d_key.release();
+  c->d_wkey.release();
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int gcre_set_top_k(gcre_ctx* c, int top_k) {
+  if (!c) return GCRE_ERR_ARG;
+  if (top_k < 1) return fail(c, GCRE_ERR_ARG, "top_k must be >= 1");
+  c->top_k = top_k;
+  return GCRE_OK;
+}
+
+int gcre_width_ul(const gcre_ctx* c) { return c ? c->g.W : GCRE_ERR_ARG; }
+int gcre_vlen(const gcre_ctx* c) { return c ? c->g.W * c->g.method : GCRE_ERR_ARG; }
+
+int gcre_set_value_table(gcre_ctx* c, const double* table, int nrow, int ncol, int col_major) {
+  if (!c || (!table && nrow > 0 && ncol > 0) || nrow < 0 || ncol < 0) return fail(c, GCRE_ERR_ARG, "bad value table");
+  (void)hipSetDevice(c->device);
+  const Geometry& g = c->g;
+  const int n = g.n;
+  // the reference pads the table to (n+1)x(n+1) with -1 (join_base.cpp:67-78); the device keeps it
+  // diagonal-major and also covers carrier counts up to the padded word width with -1
+  auto VT = [&](int r, int q) -> double {
+    if (r > n || q > n || r >= nrow || q >= ncol) return -1.0;
+    return col_major ? table[(size_t)q * nrow + r] : table[(size_t)r * ncol + q];
+  };
+  const size_t TD = (size_t)g.TD, NT = tri(TD);
+  std::vector<double> dvt(NT);
+  for (size_t t = 0; t < TD; t++) {
+    double* d = dvt.data() + tri(t);
+    for (size_t i = 0; i <= t; i++) d[i] = VT((int)i, (int)(t - i));
+  }
+  for (void** p : {(void**)&c->d_dvt, (void**)&c->d_t32, (void**)&c->d_dmax})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  HIP_TRY(c, hipMalloc((void**)&c->d_dvt, NT * 8));
+  HIP_TRY(c, hipMemcpy(c->d_dvt, dvt.data(), NT * 8, hipMemcpyHostToDevice));
+  if (g.method == 1) {
+    // null lookups of method 1 only ever feed "if (p > cur) cur = (float)p" with cur starting at 0
+    // (methods.h:96-103): pre-round to f32 and clamp everything that can never win to +0
+    std::vector<float> t32(NT);
+    for (size_t i = 0; i < NT; i++) {
+      const float f = (float)dvt[i];
+      t32[i] = (f > 0.0f) ? f : 0.0f;
+    }
+    HIP_TRY(c, hipMalloc((void**)&c->d_t32, NT * 4));
+    HIP_TRY(c, hipMemcpy(c->d_t32, t32.data(), NT * 4, hipMemcpyHostToDevice));
+  } else {
+    // compute_value_table_max, methods.h:110-118: max(vt[r][c], vt[c][r]) with std::max semantics
+    std::vector<double> dmax(NT);
+    for (size_t t = 0; t < TD; t++) {
+      const double* d = dvt.data() + tri(t);
+      double* m = dmax.data() + tri(t);
+      for (size_t i = 0; i <= t; i++) {
+        const double a = d[i], b = d[t - i];
+        m[i] = (a < b) ? b : a;
+      }
+    }
+    HIP_TRY(c, hipMalloc((void**)&c->d_dmax, NT * 8));
+    HIP_TRY(c, hipMemcpy(c->d_dmax, dmax.data(), NT * 8, hipMemcpyHostToDevice));
+  }
+  c->have_table = true;
+  return GCRE_OK;
+}
+
+int gcre_set_perm_cases(gcre_ctx* c, const int32_t* perms, int nrow, int ncol, int col_major) {
+  if (!c || nrow < 0 || ncol < 0) return fail(c, GCRE_ERR_ARG, "bad permutation matrix");
+  (void)hipSetDevice(c->device);
+  const Geometry& g = c->g;
+  if (g.K == 0) { c->have_perms = true; return GCRE_OK; }
+  // too few rows are reused cyclically (join_base.cpp:116-123) -- with zero rows the reference divides by zero
+  if (nrow == 0 || !perms) return fail(c, GCRE_ERR_ASSERT, "assertion: iterations > 0 but no permuted cases");
+  if (ncol != g.n) return fail(c, GCRE_ERR_ASSERT, "assertion: permuted cases must have num_cases + num_ctrls columns");
+  if (nrow > g.K && !c->quiet) std::printf("  ** WARN more permuted cases than iterations, input will be truncated\n");   // :89-90
+  if (nrow < g.K && !c->quiet)
+    std::printf("  ** WARN not enough permuted cases, some will be reused to match iterations - hope this is for testing!\n");
+  const int used = std::min(nrow, g.K);
+  std::vector<int32_t> rows;
+  const int32_t* src = perms;   // row-major: the first `used` rows are contiguous
+  if (col_major) {              // R matrix: gather the rows we need
+    rows.resize((size_t)used * ncol);
+    for (int r = 0; r < used; r++)
+      for (int q = 0; q < ncol; q++) rows[(size_t)r * ncol + q] = perms[(size_t)q * nrow + r];
+    src = rows.data();
+  }
+  int32_t* d_in = nullptr;
+  const size_t bytes = (size_t)used * ncol * 4;
+  HIP_TRY(c, hipMalloc((void**)&d_in, bytes));
+  hipError_t e = hipMemcpyAsync(d_in, src, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = launch_masks_from_ints(d_in, used, ncol, 0, g, c->d_masks, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_in);
+  if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("set_perm_cases: ") + hipGetErrorString(e));
+  c->have_perms = true;
+  return GCRE_OK;
+}
+
+int gcre_set_perm_masks(gcre_ctx* c, const uint64_t* masks, int nrow) {
+  if (!c || nrow < 0) return fail(c, GCRE_ERR_ARG, "bad mask matrix");
+  (void)hipSetDevice(c->device);
+  const Geometry& g = c->g;
+  if (g.K == 0) { c->have_perms = true; return GCRE_OK; }
+  if (nrow == 0 || !masks) return fail(c, GCRE_ERR_ASSERT, "assertion: iterations > 0 but no permuted cases");
+  const int used = std::min(nrow, g.K);
+  uint64_t* d_in = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_in, (size_t)used * g.W * 8));
+  hipError_t e = hipMemcpyAsync(d_in, masks, (size_t)used * g.W * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = launch_masks_from_words(d_in, used, g, c->d_masks, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_in);
+  if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("set_perm_masks: ") + hipGetErrorString(e));
+  c->have_perms = true;
+  return GCRE_OK;
+}
+
+// ---- path sets ----
+gcre_pathset* gcre_pathset_zeros(gcre_ctx* c, int64_t nrows) {
+  if (!c) return nullptr;
+  (void)hipSetDevice(c->device);
+  return new_pathset(c, nrows, true);
+}
+
+gcre_pathset* gcre_pathset_from_dense(gcre_ctx* c, const int32_t* data, int64_t nrow, int ncol, int col_major) {
+  if (!c) return nullptr;
+  (void)hipSetDevice(c->device);
+  if (nrow < 0 || ncol < 0 || (!data && nrow > 0 && ncol > 0)) {
+    fail(c, GCRE_ERR_ARG, "bad dense matrix");
+    return nullptr;
+  }
+  // check_index(data[r].size(), width_ul*64), gcre_paths.h:63: every column must fit the mask words
+  if (ncol > c->g.W * 64) {
+    fail(c, GCRE_ERR_RANGE, "assertion: more data columns than mask bits");
+    return nullptr;
+  }
+  gcre_pathset* ps = new_pathset(c, nrow, true);
+  if (!ps || nrow == 0 || ncol == 0) return ps;
+  int32_t* d_in = nullptr;
+  const size_t bytes = (size_t)nrow * ncol * 4;
+  hipError_t e = hipMalloc((void**)&d_in, bytes);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in, data, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = launch_pack_dense(d_in, nrow, ncol, col_major, ps->d_rows, c->g.S, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (d_in) (void)hipFree(d_in);
+  if (e != hipSuccess) {
+    fail(c, GCRE_ERR_DEVICE, std::string("pathset_from_dense: ") + hipGetErrorString(e));
+    gcre_pathset_free(ps);
+    return nullptr;
+  }
+  return ps;
+}
+
+gcre_pathset* gcre_pathset_from_words(gcre_ctx* c, const uint64_t* rows, int64_t nrows) {
+  if (!c) return nullptr;
+  (void)hipSetDevice(c->device);
+  gcre_pathset* ps = new_pathset(c, nrows, true);
+  if (!ps || nrows == 0) return ps;
+  const Geometry& g = c->g;
+  // host rows are [half][W]; device rows are [half][Wp]
+  std::vector<uint64_t> dev((size_t)nrows * g.S, 0);
+  for (int64_t r = 0; r < nrows; r++)
+    for (int h = 0; h < g.method; h++)
+      std::memcpy(&dev[(size_t)r * g.S + (size_t)h * g.Wp], &rows[(size_t)r * g.W * g.method + (size_t)h * g.W],
+                  (size_t)g.W * 8);
+  if (hipMemcpy(ps->d_rows, dev.data(), dev.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+    fail(c, GCRE_ERR_DEVICE, "pathset_from_words: copy failed");
+    gcre_pathset_free(ps);
+    return nullptr;
+  }
+  return ps;
+}
+
+gcre_pathset* gcre_pathset_select(gcre_ctx* c, const gcre_pathset* from, const int32_t* idx, int64_t n) {
+  if (!c || !from || from->ctx != c || n < 0 || (!idx && n > 0)) {
+    fail(c, GCRE_ERR_ARG, "bad select arguments");
+    return nullptr;
+  }
+  (void)hipSetDevice(c->device);
+  for (int64_t i = 0; i < n; i++)   // check_index(indices[k], size), gcre_paths.h:85
+    if (idx[i] < 0 || idx[i] >= from->nrows) {
+      fail(c, GCRE_ERR_RANGE, "assertion: select index out of range");
+      return nullptr;
+    }
+  gcre_pathset* ps = new_pathset(c, n, false);
+  if (!ps || n == 0) return ps;
+  int32_t* d_idx = nullptr;
+  hipError_t e = hipMalloc((void**)&d_idx, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = launch_select(from->d_rows, d_idx, n, c->g.S, ps->d_rows, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (d_idx) (void)hipFree(d_idx);
+  if (e != hipSuccess) {
+    fail(c, GCRE_ERR_DEVICE, std::string("pathset_select: ") + hipGetErrorString(e));
+    gcre_pathset_free(ps);
+    return nullptr;
+  }
+  return ps;
+}
+
+int64_t gcre_pathset_size(const gcre_pathset* ps) { return ps ? ps->nrows : GCRE_ERR_ARG; }
+
+int gcre_pathset_read(gcre_ctx* c, const gcre_pathset* ps, uint64_t* out_rows) {
+  if (!c || !ps || ps->ctx != c || (!out_rows && ps->nrows > 0)) return fail(c, GCRE_ERR_ARG, "bad read arguments");
+  (void)hipSetDevice(c->device);
+  const Geometry& g = c->g;
+  if (ps->nrows == 0) return GCRE_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<uint64_t> dev((size_t)ps->nrows * g.S);
+  HIP_TRY(c, hipMemcpy(dev.data(), ps->d_rows, dev.size() * 8, hipMemcpyDeviceToHost));
+  for (int64_t r = 0; r < ps->nrows; r++)
+    for (int h = 0; h < g.method; h++)
+      std::memcpy(&out_rows[(size_t)r * g.W * g.method + (size_t)h * g.W], &dev[(size_t)r * g.S + (size_t)h * g.Wp],
+                  (size_t)g.W * 8);
+  return GCRE_OK;
+}
+
+void gcre_pathset_free(gcre_pathset* ps) {
+  if (!ps) return;
+  if (ps->ctx) {
+    (void)hipSetDevice(ps->ctx->device);
+    if (ps->ctx->stream) (void)hipStreamSynchronize(ps->ctx->stream);
+  }
+  if (ps->d_rows) (void)hipFree(ps->d_rows);
+  delete ps;
+}
+
+int gcre_join(gcre_ctx* c, int path_length, const int32_t* uid_count, const int64_t* uid_location, int64_t n_uids,
+              const int32_t* signs, int64_t n_signs, const gcre_pathset* paths0, const gcre_pathset* paths1,
+              gcre_pathset* res, const gcre_join_opts* opts, gcre_result* out) {
+  if (!c || !out || n_uids < 0 || (n_uids > 0 && (!uid_count || !uid_location)) || n_signs < 0 ||
+      (n_signs > 0 && !signs))
+    return fail(c, GCRE_ERR_ARG, "bad join arguments");
+  (void)hipSetDevice(c->device);
+  JoinPlan jp{path_length, uid_count, uid_location, n_uids, signs, n_signs, paths0, paths1, res,
+              opts ? opts->shard_begin : 0, opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
+  int rc = run_join(c, jp, out);
+  if (rc != GCRE_OK) gcre_result_free(out);
+  return rc;
+}
+
+void gcre_result_free(gcre_result* r) {
+  if (!r) return;
+  std::free(r->scores);
+  std::free(r->src);
+  std::free(r->trg);
+  std::free(r->cases);
+  std::free(r->ctrls);
+  std::free(r->null_max);
+  std::memset(r, 0, sizeof *r);
+}
+
+int gcre_get_profile(const gcre_ctx* c, gcre_profile* out) {
+  if (!c || !out) return GCRE_ERR_ARG;
+  *out = c->prof;
+  return GCRE_OK;
+}
+
+int gcre_resolve_count_locs(const int32_t* trg_uids, int64_t n_uids, const int32_t* keys, const int32_t* counts,
+                            const int32_t* locations, int64_t n_keys, int32_t* out_count, int64_t* out_location) {
+  if (n_uids < 0 || n_keys < 0 || (n_uids > 0 && (!trg_uids || !out_count || !out_location)) ||
+      (n_keys > 0 && (!keys || !counts || !locations)))
+    return GCRE_ERR_ARG;
+  std::unordered_map<int32_t, std::pair<int32_t, int32_t>> map;   // count_locs, wrapper.cpp:106-112
+  map.reserve((size_t)n_keys * 2);
+  for (int64_t i = 0; i < n_keys; i++) map[keys[i]] = {counts[i], locations[i]};
+  for (int64_t k = 0; k < n_uids; k++) {
+    auto it = map.find(trg_uids[k]);   // a missing key reads as {0, 0}, wrapper.cpp:124-126
+    out_count[k] = (it == map.end()) ? 0 : it->second.first;
+    out_location[k] = (it == map.end()) ? 0 : it->second.second;
+  }
+  return GCRE_OK;
+}
+
+int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5]) {
+  if (!c || !in || !out) return fail(c, GCRE_ERR_ARG, "bad process_paths arguments");
+  (void)hipSetDevice(c->device);
+  for (int i = 0; i < 5; i++) {
+    std::memset(&out[i], 0, sizeof out[i]);
+    out[i].n = -1;   // NULL list entry, wrapper.cpp:223
+  }
+  const int L = in->path_length;
+  gcre_profile total{};
+  auto add_prof = [&]() {
+    total.null_kernel_ms += c->prof.null_kernel_ms;
+    total.null_kernel_launches += c->prof.null_kernel_launches;
+    total.stats_kernel_ms += c->prof.stats_kernel_ms;
+    total.select_ms += c->prof.select_ms;
+    total.total_ms += c->prof.total_ms;
+    total.paths += c->prof.paths;
+    total.scores += c->prof.scores;
+    total.null_alg_bytes += c->prof.null_alg_bytes;
+  };
+
+  int rc = gcre_set_value_table(c, in->value_table, in->vt_rows, in->vt_cols, in->vt_col_major);   // wrapper.cpp:213
+  if (rc != GCRE_OK) return rc;
+  rc = gcre_set_perm_cases(c, in->perm_cases, in->perm_rows, c->g.n, in->perm_col_major);          // wrapper.cpp:214
+  if (rc != GCRE_OK) return rc;
+
+  gcre_pathset *parsed1 = nullptr, *parsed2 = nullptr, *paths1 = nullptr, *paths2 = nullptr, *paths3 = nullptr;
+  std::vector<gcre_pathset*> temps;
+  auto cleanup = [&]() {
+    for (auto* p : temps) gcre_pathset_free(p);
+    for (auto* p : {parsed1, parsed2, paths1, paths2, paths3}) gcre_pathset_free(p);
+  };
+  auto total_paths = [](const gcre_level& lv) {
+    int64_t t = 0;
+    for (int64_t i = 0; i < lv.n_uids; i++) t += std::max(lv.uid_count[i], 0);
+    return t;
+  };
+  auto join = [&](int plen, const gcre_level& lv, const gcre_pathset* p0, const gcre_pathset* p1, gcre_pathset* res,
+                  gcre_result* o) -> int {
+    JoinPlan jp{plen, lv.uid_count, lv.uid_location, lv.n_uids, lv.signs, lv.n_signs, p0, p1, res, 0, 0, nullptr};
+    gcre_result tmp;
+    int r = run_join(c, jp, &tmp);
+    if (r != GCRE_OK) { gcre_result_free(&tmp); return r; }
+    add_prof();
+    if (o) *o = tmp; else gcre_result_free(&tmp);
+    return GCRE_OK;
+  };
+#define PP_REQUIRE(ptr)            \
+  do {                             \
+    if (!(ptr)) { cleanup(); return c->last_code != GCRE_OK ? c->last_code : GCRE_ERR_DEVICE; } \
+  } while (0)
+#define PP_TRY(expr)               \
+  do {                             \
+    int r__ = (expr);              \
+    if (r__ != GCRE_OK) { cleanup(); return r__; } \
+  } while (0)
+
+  const int ncol = c->g.n;
+  parsed1 = gcre_pathset_from_dense(c, in->data1, in->data1_rows, ncol, in->data_col_major);   // wrapper.cpp:216-217
+  PP_REQUIRE(parsed1);
+
+  if (L >= 1) {   // wrapper.cpp:225-244
+    if (!c->quiet) std::printf("Processing Path Length: %d\n", 1);
+    paths1 = new_pathset(c, total_paths(in->level[0]), true);
+    PP_REQUIRE(paths1);
+    gcre_pathset* zero1 = gcre_pathset_zeros(c, in->n_data_inds[0]);
+    PP_REQUIRE(zero1);
+    temps.push_back(zero1);
+    gcre_pathset* input1 = gcre_pathset_select(c, parsed1, in->data_inds[0], in->n_data_inds[0]);
+    PP_REQUIRE(input1);
+    temps.push_back(input1);
+    PP_TRY(join(1, in->level[0], zero1, input1, paths1, nullptr));   // result discarded, wrapper.cpp:233
+
+    if (!c->quiet) std::printf("Processing Path Length: %d\n", 1);
+    gcre_pathset* zero2 = gcre_pathset_zeros(c, in->n_data_inds[1]);
+    PP_REQUIRE(zero2);
+    temps.push_back(zero2);
+    parsed2 = gcre_pathset_from_dense(c, in->data2, in->data2_rows, ncol, in->data_col_major);
+    PP_REQUIRE(parsed2);
+    gcre_pathset* input2 = gcre_pathset_select(c, parsed2, in->data_inds[1], in->n_data_inds[1]);
+    PP_REQUIRE(input2);
+    temps.push_back(input2);
+    PP_TRY(join(1, in->level[1], zero2, input2, nullptr, &out[0]));
+  }
+  if (L >= 2) {   // wrapper.cpp:246-253
+    if (!c->quiet) std::printf("Processing Path Length: %d\n", 2);
+    paths2 = new_pathset(c, total_paths(in->level[2]), true);
+    PP_REQUIRE(paths2);
+    // the reference reads data_idx2 from r_data_inds3 (wrapper.cpp:207); R passes identical vectors
+    gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
+    PP_REQUIRE(input);
+    temps.push_back(input);
+    PP_TRY(join(2, in->level[2], paths1, input, paths2, &out[1]));
+  }
+  if (L >= 3) {   // wrapper.cpp:255-262
+    if (!c->quiet) std::printf("Processing Path Length: %d\n", 3);
+    paths3 = new_pathset(c, total_paths(in->level[3]), true);
+    PP_REQUIRE(paths3);
+    gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
+    PP_REQUIRE(input);
+    temps.push_back(input);
+    PP_TRY(join(3, in->level[3], paths2, input, paths3, &out[2]));
+  }
+  if (L >= 4) {   // wrapper.cpp:264-269
+    if (!c->quiet) std::printf("Processing Path Length: %d\n", 4);
+    PP_TRY(join(4, in->level[4], paths3, paths2, nullptr, &out[3]));
+  }
+  if (L >= 5) {   // wrapper.cpp:271-276
+    if (!c->quiet) std::printf("Processing Path Length: %d\n", 5);
+    PP_TRY(join(5, in->level[5], paths3, paths3, nullptr, &out[4]));
+  }
+  if (!c->quiet) std::printf("[success]\n");   // wrapper.cpp:278
+  cleanup();
+  c->prof = total;
+  return GCRE_OK;
+#undef PP_REQUIRE
+#undef PP_TRY
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// gcre_kernels.h -- launch interface between the host library (gcre_host.hip) and the gfx950 kernels
+// (gcre_kernels.hip).  Internal; the public boundary is include/gcre_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gcre {
+
+// Device layout (DESIGN.md "Data layout in HBM"):
+//   path rows : uint64 [rows][S], S = M * Wp, Wp = ceil(n/64) rounded up to 4 words (32-byte chunks);
+//               method 2 keeps the (+) half in words [0,Wp) and the (-) half in [Wp,2Wp)
+//   masks     : uint32 [W32p][Kpad], W32p = 2*Wp dwords, word-major / permutation-minor
+//               (the reference's layout, src/join_base.cpp:109, at 32-bit granularity), Kpad % 512 == 0
+//   tables    : "diagonal-major": entry [t][i] = table[i][t-i] at index t*(t+1)/2 + i, t = carriers on the
+//               path -- one path only ever touches one diagonal (src/methods.h:96-100)
+struct Geometry {
+  int method;   // M
+  int n;        // patients
+  int n_cases;
+  int W;        // ceil(n/64)
+  int Wp;       // padded words per half
+  int S;        // row stride in uint64
+  int K;        // iterations requested
+  int Kpad;
+  int TD;       // number of table diagonals = 64*Wp + 1
+};
+
+constexpr int kPermTileMax = 512;      // Kpad granularity
+constexpr int kNullBlock = 256;        // threads per block of the null kernel
+
+struct NullArgs {
+  const uint32_t* p0;       // paths0 rows (dword view)
+  const uint32_t* p1;       // paths1 rows
+  const uint32_t* masks;    // [W32p][Kpad]
+  const uint32_t* row0;     // per joined path in this launch: row of paths0
+  const uint32_t* row1;     // row of paths1, bit 31 = swap (+)/(-) halves of path1 (method 2)
+  const uint32_t* tot;      // M entries per path: carriers (M=1) or carriers in (+),(-) halves (M=2)
+  const float* t32;         // M=1: sanitised f32 null table, diagonal-major
+  const double* d64;        // M=2: f64 vtmax, diagonal-major
+  uint32_t* null_bits;      // [Kpad] running maxima as u32 bit patterns of non-negative floats
+  int64_t npaths;           // joined paths in this launch
+  int64_t npt;              // path tiles
+  int S32;                  // row stride in dwords
+  int W32p;                 // dwords per half
+  int Kpad;
+  int nkt;                  // permutation tiles
+  int pgroups;              // blocks per permutation tile
+};
+
+struct NullConfig {
+  int R;        // permutations per lane
+  int TPW;      // joined paths per wave per tile
+  int perm_tile;   // 64 * R
+  int path_tile;   // 4 * TPW
+};
+
+NullConfig null_config(int method, int K);
+// grid is derived from the args (nkt * pgroups blocks)
+hipError_t launch_null(const NullArgs& a, int method, const NullConfig& cfg, hipStream_t stream);
+
+hipError_t launch_pack_dense(const int32_t* data, int64_t nrow, int ncol, int col_major, uint64_t* rows, int S,
+                             hipStream_t stream);
+hipError_t launch_select(const uint64_t* from, const int32_t* idx, int64_t n, int S, uint64_t* out, hipStream_t stream);
+hipError_t launch_masks_from_ints(const int32_t* perms, int nrows_in, int ncol, int col_major, const Geometry& g,
+                                  uint32_t* masks, hipStream_t stream);
+hipError_t launch_masks_from_words(const uint64_t* packed, int nrows_in, const Geometry& g, uint32_t* masks,
+                                   hipStream_t stream);
+
+// joined-path ordinal -> (row of paths0, row of paths1 | swap<<31)
+hipError_t launch_expand(const int64_t* path_idx, const int64_t* location, int64_t n_uids, const int32_t* signs,
+                         int path_length, int method, int64_t first, int64_t count, uint32_t* row0, uint32_t* row1,
+                         hipStream_t stream);
+
+struct StatsArgs {
+  const uint64_t* p0;
+  const uint64_t* p1;
+  const uint32_t* row0;
+  const uint32_t* row1;
+  const uint64_t* case_mask;   // [Wp]
+  const double* dvt;           // f64 value table, diagonal-major
+  uint64_t* key;               // order-preserving u64 image of the real score (0 = never a candidate)
+  uint32_t* tot;               // M per path
+  uint32_t* cases;
+  uint32_t* ctrls;
+  uint64_t* res;               // kept rows, indexed by absolute ordinal (first + i), or nullptr
+  int64_t first;
+  int64_t count;
+  int S;
+  int Wp;
+};
+hipError_t launch_stats(const StatsArgs& a, int method, hipStream_t stream);
+
+// ---- top-k selection over key[0..count) ----
+hipError_t launch_hist(const uint64_t* key, int64_t count, int shift, uint64_t prefix, uint32_t* hist256,
+                       hipStream_t stream);
+// appends every i with key[i] > thr (any order) to out[], counter in *n_out
+hipError_t launch_collect_gt(const uint64_t* key, int64_t count, uint64_t thr, uint32_t* out, uint32_t* n_out,
+                             uint32_t cap, hipStream_t stream);
+// per 1024-entry chunk: number of key[i] == thr
+hipError_t launch_eq_count(const uint64_t* key, int64_t count, uint64_t thr, uint32_t* chunk_cnt, hipStream_t stream);
+// first `m` (in index order) entries with key[i] == thr, written at out[rank]; chunk_base = exclusive scan of chunk_cnt
+hipError_t launch_eq_collect(const uint64_t* key, int64_t count, uint64_t thr, const uint32_t* chunk_base, uint32_t m,
+                             uint32_t* out, hipStream_t stream);
+hipError_t launch_gather_winners(const uint32_t* sel, uint32_t nsel, const uint64_t* key, const uint32_t* cases,
+                                 const uint32_t* ctrls, const uint32_t* row0, const uint32_t* row1, uint64_t* o_key,
+                                 uint32_t* o_cases, uint32_t* o_ctrls, uint32_t* o_row0, uint32_t* o_row1,
+                                 hipStream_t stream);
+hipError_t launch_fill_u32(uint32_t* p, int64_t n, uint32_t v, hipStream_t stream);
+hipError_t launch_max_merge(uint32_t* dst, const uint32_t* src, int n, hipStream_t stream);
+
+}  // namespace gcre

@@ -1,0 +1,160 @@
+/*
+ * gcre_hip.h -- C ABI of libgcre_hip.so, the MI355X (gfx950) implementation of geneticsCRE's
+ * permutation-tested path-join scorer.
+ *
+ * This is the drop-in boundary: the entry points below are what a replacement for the reference's
+ * src/wrapper.cpp binds (R .Call shim) and what the Python host in
+ * geneticscre_amd/api.py binds through ctypes.  Plain pointers and sizes only; nothing throws across
+ * the boundary; every function returns 0 on success or a negative gcre_status, and the message is
+ * available from gcre_last_error().  A context is used from one host thread at a time.
+ *
+ * Reference interface replaced (paths relative to /root/reference):
+ *   JoinExec ctor / setValueTable / setPermutedCases   src/join_base.cpp:37-125, src/gcre.h:103-180
+ *   PathSet ctor / load / select                        src/gcre_paths.h:19-92
+ *   JoinExec::join (+ JoinMethod1/2::score_permute)     src/join_base.cpp:189-264, src/methods.h:58-232
+ *   ProcessPaths (the 39-argument driver)               src/wrapper.cpp:177-281
+ */
+#ifndef GCRE_HIP_H
+#define GCRE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCRE_ABI_VERSION 1
+
+typedef enum {
+  GCRE_OK = 0,
+  GCRE_ERR_ASSERT = -1,   /* std::logic_error("assertion") in the reference (gcre_types.h:58-66) */
+  GCRE_ERR_RANGE = -2,    /* std::out_of_range("assertion")            (gcre_types.h:68-76) */
+  GCRE_ERR_DEVICE = -3,   /* HIP runtime failure or no gfx950 device */
+  GCRE_ERR_ARG = -4       /* NULL / malformed argument */
+} gcre_status;
+
+typedef struct gcre_ctx gcre_ctx;           /* JoinExec   -- src/gcre.h:103-180 */
+typedef struct gcre_pathset gcre_pathset;   /* PathSet    -- src/gcre_paths.h:10-98, rows live in HBM */
+
+/* joined_res + Score -- src/gcre_types.h:32-48.  Arrays are owned by the library until gcre_result_free. */
+typedef struct {
+  int32_t n;            /* entries, <= top_k, ascending score; may hold the {-inf,-1,-1,0,0} sentinel
+                           when the level has fewer than top_k scorable paths (join_base.cpp:194) */
+  double* scores;
+  int32_t* src;         /* Score.src = row of paths0 / uid index (methods.h:92) */
+  int32_t* trg;         /* Score.trg = row of paths1 */
+  int32_t* cases;
+  int32_t* ctrls;
+  int32_t n_perm;       /* = iterations requested */
+  float* null_max;      /* per-permutation maximum over this level's paths, f32 (methods.h:101-102) */
+} gcre_result;
+
+/* Optional knobs of one join.  Zero-initialise for the reference behaviour. */
+typedef struct {
+  int64_t shard_begin;  /* joined-path ordinal range scored on THIS device: [shard_begin, shard_end). */
+  int64_t shard_end;    /* shard_end <= 0 means "all paths".  Kept path rows are always produced in full. */
+  void* d_null_out;     /* optional device pointer to iterations floats: receives this shard's null maxima
+                           (for an RCCL MAX all-reduce by the caller); may be NULL */
+} gcre_join_opts;
+
+/* Timing of the last join / process_paths call, measured with HIP events on the library's stream. */
+typedef struct {
+  double null_kernel_ms;      /* sum over launches of the permutation (null) kernel */
+  int64_t null_kernel_launches;
+  double stats_kernel_ms;     /* real-label scoring + kept-row materialisation */
+  double select_ms;           /* top-k selection */
+  double total_ms;            /* whole device region */
+  int64_t paths;              /* joined paths scored on this device */
+  int64_t scores;             /* paths x iterations */
+  double null_alg_bytes;      /* algorithmic HBM bytes of the null kernel launches */
+} gcre_profile;
+
+/* ---- context: JoinExec::JoinExec, src/join_base.cpp:37-59.  method 1 = unsigned, 2 = signed. ---- */
+gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int device);
+void gcre_destroy(gcre_ctx* ctx);
+const char* gcre_last_error(const gcre_ctx* ctx);   /* ctx may be NULL: error of the last failed gcre_create */
+int gcre_abi_version(void);
+
+int gcre_set_top_k(gcre_ctx* ctx, int top_k);        /* JoinExec::top_k, src/gcre.h:120 (default 12) */
+int gcre_width_ul(const gcre_ctx* ctx);              /* 64-bit words per case/control mask, ceil(n/64) */
+int gcre_vlen(const gcre_ctx* ctx);                  /* words per path row as seen by the host = width * method */
+
+/* JoinExec::setValueTable, src/join_base.cpp:62-80.  nrow x ncol doubles; col_major != 0 for an R matrix. */
+int gcre_set_value_table(gcre_ctx* ctx, const double* table, int nrow, int ncol, int col_major);
+
+/* JoinExec::setPermutedCases, src/join_base.cpp:85-125.  nrow x ncol ints, 1 = label kept. */
+int gcre_set_perm_cases(gcre_ctx* ctx, const int32_t* perms, int nrow, int ncol, int col_major);
+
+/* Extension: the same masks already packed, nrow x width_ul words, bit c of row r = "patient c is a case
+ * under permutation r" (what setPermutedCases derives).  Same row reuse / truncation rules. */
+int gcre_set_perm_masks(gcre_ctx* ctx, const uint64_t* masks, int nrow);
+
+/* ---- path sets ---- */
+gcre_pathset* gcre_pathset_zeros(gcre_ctx* ctx, int64_t nrows);                    /* createPathSet, join_base.cpp:157-161 */
+gcre_pathset* gcre_pathset_from_dense(gcre_ctx* ctx, const int32_t* data, int64_t nrow, int ncol,
+                                      int col_major);                               /* PathSet::load, gcre_paths.h:56-78 */
+gcre_pathset* gcre_pathset_from_words(gcre_ctx* ctx, const uint64_t* rows, int64_t nrows);   /* packed rows, vlen words each */
+gcre_pathset* gcre_pathset_select(gcre_ctx* ctx, const gcre_pathset* from, const int32_t* idx,
+                                  int64_t n);                                       /* PathSet::select, gcre_paths.h:82-92 */
+int64_t gcre_pathset_size(const gcre_pathset* ps);
+int gcre_pathset_read(gcre_ctx* ctx, const gcre_pathset* ps, uint64_t* out_rows);   /* device -> host, size x vlen words */
+void gcre_pathset_free(gcre_pathset* ps);
+
+/*
+ * JoinExec::join, src/join_base.cpp:189-264.
+ *   uid_count / uid_location : uid_ref.count / .location per row of paths0 (src/gcre_types.h:50-56)
+ *   signs                    : UidRelSet::signs, used by method 2 through need_flip (src/gcre.h:71-81)
+ *   res                      : receives the joined rows (size must equal the total path count) or NULL
+ * Ties between equal scores are resolved towards the smaller joined-path ordinal ("Ties").
+ */
+int gcre_join(gcre_ctx* ctx, int path_length,
+              const int32_t* uid_count, const int64_t* uid_location, int64_t n_uids,
+              const int32_t* signs, int64_t n_signs,
+              const gcre_pathset* paths0, const gcre_pathset* paths1, gcre_pathset* res,
+              const gcre_join_opts* opts, gcre_result* out);
+void gcre_result_free(gcre_result* r);
+
+int gcre_get_profile(const gcre_ctx* ctx, gcre_profile* out);
+
+/*
+ * ProcessPaths, src/wrapper.cpp:177-281: the whole six-join sequence on plain arrays.
+ * Level order of the six uid tables: 1a, 1b, 2, 3, 4, 5 (wrapper.cpp:177-182).  uid_count/uid_location are the
+ * already-resolved count_locs (wrapper.cpp:106-132; gcre_resolve_count_locs below does that lookup).
+ */
+typedef struct {
+  const int32_t* uid_count;
+  const int64_t* uid_location;
+  int64_t n_uids;
+  const int32_t* signs;
+  int64_t n_signs;
+} gcre_level;
+
+typedef struct {
+  gcre_level level[6];
+  const int32_t* data_inds[4];   /* 1a, 1b, 2, 3 -- 0-based rows of data1 / data2 (wrapper.cpp:205-208) */
+  int64_t n_data_inds[4];
+  const int32_t* data1;          /* genes x patients */
+  int64_t data1_rows;
+  const int32_t* data2;
+  int64_t data2_rows;
+  int data_col_major;            /* R matrices are column-major */
+  const double* value_table;
+  int vt_rows, vt_cols, vt_col_major;
+  const int32_t* perm_cases;     /* iterations x patients, may be NULL with 0 rows */
+  int perm_rows, perm_col_major;
+  int path_length;               /* 1..5 */
+} gcre_pp_input;
+
+/* out[0..4] = lst1..lst5; entries above path_length have n = -1 (R sees NULL, wrapper.cpp:223). */
+int gcre_process_paths(gcre_ctx* ctx, const gcre_pp_input* in, gcre_result out[5]);
+
+/* uid resolution of assemble_uids (src/wrapper.cpp:106-132): row k takes (count, location) of the entry
+ * keyed by trg_uids[k]; missing keys give (0, 0). */
+int gcre_resolve_count_locs(const int32_t* trg_uids, int64_t n_uids,
+                            const int32_t* keys, const int32_t* counts, const int32_t* locations, int64_t n_keys,
+                            int32_t* out_count, int64_t* out_location);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

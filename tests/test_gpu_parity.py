@@ -1,0 +1,58 @@
+"""HIP path vs the CPU oracle through the C ABI, bit-exact (run on a real MI355X: pytest -m gpu)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from geneticscre_amd import api
+from geneticscre_amd.harness_io import read_problem
+from geneticscre_amd.synth import make_problem
+from helpers import assert_same_result, small_table
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def run_both(p):
+    want = oracle.process_paths(p, order="canonical")
+    got = api.process_paths(p)
+    return got, want
+
+
+@pytest.mark.parametrize("case", json.load(open(os.path.join(GOLD, "appendix_b_expected.json")))["cases"],
+                         ids=lambda c: c["name"])
+def test_appendix_b_golden(case):
+    """The reference's own printed outputs: score values and null maxima must match exactly;
+    ids only where the score is not tied (App. A-9)."""
+    p = read_problem(os.path.join(GOLD, "appendix_b_tiny.txt"), method=case["method"], iterations=case["iterations"],
+                     top_k=case["top_k"], path_length=case["path_length"])
+    got = api.process_paths(p)["lst4"]
+    exp_scores = np.array([float(s) for s in case["scores"]])
+    np.testing.assert_array_equal(got.scores, exp_scores)
+    np.testing.assert_array_equal(got.null, np.array(case["null"], dtype=np.float32))
+    ids = {(s, tuple(i)) for s, i in zip(exp_scores.tolist(), case["ids"])}
+    for s, a, b in zip(got.scores.tolist(), got.src.tolist(), got.trg.tolist()):
+        if (exp_scores == s).sum() == 1:
+            assert (s, (a, b)) in ids
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+@pytest.mark.parametrize("n_perm", [0, 3, 100, 130, 700])
+def test_process_paths_matches_oracle(method, n_perm):
+    nc, nt = 37, 52   # patients not a multiple of 64, nCases != nControls
+    p = make_problem(60, 150, nc, nt, n_perm, 5, method=method, top_k=9, seed=11 + n_perm,
+                     table=small_table(nc, nt, 3))
+    got, want = run_both(p)
+    for lvl in range(1, 6):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_wide_masks_and_hypergeometric_table(method):
+    """300 patients (5 words -> padded to 8), real -log hypergeometric table, top_k larger than some levels."""
+    p = make_problem(40, 90, 140, 160, 257, 4, method=method, top_k=5000, seed=5)
+    got, want = run_both(p)
+    for lvl in range(1, 5):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
