@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- path x permutation scores/sec of the MI355X path-join scorer.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config roofline]
+
+One "step" = one pass of the hot path (the ProcessPaths join sequence, reference src/wrapper.cpp:225-276:
+levels 1a, 1b, 2 .. path_length) over one synthetic problem whose inputs are already resident in HBM.
+For N > 1 it is launched by torch.distributed.run, one rank per GPU: every level's joined paths are sharded
+into N contiguous slices, each rank scores its slice, and the per-permutation null maxima (MAX all-reduce) and
+the top-k tables (all-gather + merge) are exchanged over RCCL.  Total work is fixed -> "strong" scaling.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GCRE_QUIET", "1")
+
+# BASELINE.json configs; "roofline" (configs[2]) is the one the headline target is quoted on
+CONFIGS = {
+    "plumbing": dict(idx=0, genes=100, edges=300, cases=100, ctrls=100, perms=100, length=3, method="method1"),
+    "subgraph": dict(idx=1, genes=5000, edges=60000, cases=500, ctrls=500, perms=1000, length=3, method="method1"),
+    "roofline": dict(idx=2, genes=17000, edges=200000, cases=2500, ctrls=2500, perms=10000, length=4, method="method1"),
+    "sharded": dict(idx=3, genes=17000, edges=200000, cases=5000, ctrls=5000, perms=100000, length=4, method="method1"),
+    "signed": dict(idx=4, genes=17000, edges=60000, cases=25000, ctrls=25000, perms=100000, length=5, method="method2"),
+}
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9        # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops/s (32-bit integer VALU)
+
+
+def build_inputs(cfg, seed, top_k):
+    from geneticscre_amd import synth
+    rng = np.random.default_rng(seed)
+    g, src, trg, sign = synth.signed_network(cfg["genes"], cfg["edges"], rng)
+    levels = synth.build_level_tables(g, src, trg, sign)
+    n = cfg["cases"] + cfg["ctrls"]
+    data1 = synth.variant_matrix(g, n, rng)
+    data2 = data1[levels.uids["1b"].src]
+    table = synth.values_table(cfg["cases"], cfg["ctrls"])
+    masks = synth.packed_case_masks(cfg["cases"], cfg["ctrls"], cfg["perms"], rng)
+    prob = synth.Problem(cfg["method"], cfg["cases"], cfg["ctrls"], cfg["length"], top_k, cfg["perms"], levels,
+                         data1, data2, table, np.zeros((0, 0), np.int32), seed)
+    return prob, masks
+
+
+def merge_topk(rows: np.ndarray, top_k: int) -> np.ndarray:
+    """rows [m, 5] = (score, src, trg, cases, ctrls) gathered from all ranks -> the reference's result table:
+    best top_k of {sentinel} U rows, ascending, ties to the smaller (src, trg) = smaller joined-path ordinal."""
+    rows = rows[rows[:, 1] >= 0]                                    # drop every rank's sentinel / padding
+    order = np.lexsort((rows[:, 2], rows[:, 1], -rows[:, 0]))       # score desc, src asc, trg asc
+    best = rows[order[:top_k]]
+    if len(best) < top_k:
+        best = np.vstack([best, [[-np.inf, -1, -1, 0, 0]]])
+    return best[::-1]
+
+
+def cpu_baseline(prob, masks, budget_s=15.0):
+    """The CPU oracle (oracle/, a port of the reference's JoinExec) timed on a bounded sample of the same
+    workload: a prefix of the deepest level's join index, all K permutations, all host cores."""
+    import oracle
+    from geneticscre_amd.uids import UidRelSet
+    threads = os.cpu_count() or 1
+    ex = oracle.OracleJoinExec(prob.method, prob.n_cases, prob.n_ctrls, prob.iterations)
+    ex.top_k, ex.nthreads = prob.top_k, threads
+    ex.set_value_table(prob.value_table)
+    ex.set_packed_masks(masks)
+    lv = prob.levels
+    # operands of the deepest level need the kept path sets: build them with zero permutations (cheap)
+    ex0 = oracle.OracleJoinExec(prob.method, prob.n_cases, prob.n_ctrls, 0)
+    ex0.top_k, ex0.nthreads = prob.top_k, threads
+    ex0.set_value_table(prob.value_table)
+    ex0.set_permuted_cases(np.zeros((0, 0), np.int32))
+    parsed1 = ex0.load(prob.data1)
+    paths1 = ex0.join(lv.uids["1a"], ex0.create_path_set(len(lv.data_inds["1a"])), parsed1[lv.data_inds["1a"]], keep=True).paths_res
+    L = prob.path_length
+    name = str(L) if L >= 2 else "1b"
+    if L >= 2:
+        paths2 = ex0.join(lv.uids["2"], paths1, parsed1[lv.data_inds["2"]], keep=True).paths_res
+    if L >= 3:
+        paths3 = ex0.join(lv.uids["3"], paths2, parsed1[lv.data_inds["3"]], keep=True).paths_res
+    ops = {"1b": None, "2": (paths1, parsed1[lv.data_inds["2"]]) if L >= 2 else None,
+           "3": (paths2, parsed1[lv.data_inds["3"]]) if L >= 3 else None,
+           "4": (paths3, paths2) if L >= 4 else None, "5": (paths3, paths3) if L >= 5 else None}
+    if ops[name] is None:
+        return None
+    p0, p1 = ops[name]
+    u = lv.uids[name]
+
+    def run(n_uids):
+        sub = UidRelSet(u.path_length, u.src[:n_uids], u.trg[:n_uids], u.count[:n_uids], u.location[:n_uids], u.signs)
+        t0 = time.perf_counter()
+        ex.join(sub, p0[:n_uids], p1, keep=False)
+        return time.perf_counter() - t0, sub.count_total_paths()
+
+    n_try = max(1, min(len(u), 64 * threads))
+    t, paths = run(n_try)
+    rate = paths * prob.iterations / max(t, 1e-9)
+    want_paths = rate * budget_s / max(prob.iterations, 1)
+    n_uids = int(min(len(u), max(n_try, np.searchsorted(u.path_idx[1:], want_paths) + 1)))
+    t, paths = run(n_uids)
+    return {"value": paths * prob.iterations / t, "unit": "scores/s", "cores": threads, "kind": "port",
+            "sample": f"level-{name} join, first {n_uids} uids = {paths} joined paths x {prob.iterations} permutations, "
+                      f"{t:.1f} s wall, oracle/gcre_oracle.cpp -O3 -march=native"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="roofline", choices=sorted(CONFIGS))
+    ap.add_argument("--edges", type=int, default=0, help="override the synthetic network's edge count")
+    ap.add_argument("--perms", type=int, default=0)
+    ap.add_argument("--top-k", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=20261003)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = dict(CONFIGS[args.config])
+    if args.edges:
+        cfg["edges"] = args.edges
+    if args.perms:
+        cfg["perms"] = args.perms
+    prob, masks = build_inputs(cfg, args.seed, args.top_k)
+
+    from geneticscre_amd import api
+    plan = api.ResidentPlan(prob, device=local_rank, packed_masks=masks)
+    K, top_k = prob.iterations, prob.top_k
+    d_null = torch.zeros(max(K, 1), dtype=torch.float32, device=dev)
+    prof_acc = {}
+
+    def on_level(name, r, shard):
+        if world == 1:
+            return r
+        # RCCL: element-wise MAX of the f32 null maxima (exact: max is associative, App. A-7) ...
+        dist.all_reduce(d_null, op=dist.ReduceOp.MAX)
+        # ... and an all-gather of every rank's top-k table, merged identically on all ranks
+        mine = torch.full((top_k + 1, 5), -1.0, dtype=torch.float64)
+        mine[:, 0] = float("-inf")
+        rows = np.stack([r.scores, r.src, r.trg, r.cases, r.ctrls], axis=1)
+        mine[: len(rows)] = torch.from_numpy(rows)
+        mine = mine.to(dev)
+        allrows = torch.empty((world * (top_k + 1), 5), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allrows, mine)
+        best = merge_topk(allrows.cpu().numpy(), top_k)
+        return api.JoinResult(best[:, 0].copy(), best[:, 1].astype(np.int32), best[:, 2].astype(np.int32),
+                              best[:, 3].astype(np.int32), best[:, 4].astype(np.int32),
+                              d_null[:K].cpu().numpy())
+
+    def step():
+        out = plan.run(rank, world, d_null_out=d_null.data_ptr(), on_level=on_level)
+        for k, v in plan.last_profile.items():
+            prof_acc[k] = prof_acc.get(k, 0) + v
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    prof_acc.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_scores = plan.total_scores()            # whole job, all ranks
+    value = total_scores * args.steps / elapsed
+    W = (prob.n_cases + prob.n_ctrls + 63) // 64
+    M = 1 if prob.method == "method1" else 2
+
+    # roofline of the dominant kernel (k_null) on THIS rank, from HIP events on the library's stream
+    null_s = prof_acc.get("null_kernel_ms", 0.0) / 1e3
+    launches = max(int(prof_acc.get("null_kernel_launches", 0)), 1)
+    alg_bytes = prof_acc.get("null_alg_bytes", 0.0)
+    my_scores = prof_acc.get("scores", 0)
+    achieved = alg_bytes / 1e9 / null_s if null_s > 0 else 0.0
+    valu_ops = my_scores * 4.0 * W * M            # 2 x (v_and_b32 + v_bcnt_u32_b32) per 64-bit word per score
+    roofline = {
+        "bound": "hbm", "kernel": "k_null", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "launches": launches, "avg_launch_ms": null_s * 1e3 / launches, "alg_bytes_per_launch": alg_bytes / launches,
+        "note": "north-star accounting (algorithmic HBM bytes / kernel time); the kernel is integer-VALU bound, see valu",
+        "valu": {"achieved": valu_ops / null_s / 1e12 if null_s > 0 else 0.0, "peak": VALU_PEAK_OPS / 1e12,
+                 "unit": "Tlane-op/s", "frac": (valu_ops / null_s / VALU_PEAK_OPS) if null_s > 0 else 0.0},
+    }
+
+    line = {
+        "metric": "path_x_permutation_scores_per_sec", "value": value, "unit": "scores/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[{cfg['idx']}] '{args.config}': synthetic STRINGdb-shaped signed network, "
+                        f"{cfg['genes']} genes / {cfg['edges']} relations, {prob.n_cases}+{prob.n_ctrls} patients, "
+                        f"{K} permutations, path length {prob.path_length}, {prob.method}",
+            "paths_per_level": {k: plan.uids[k].total_paths for k in plan.names},
+            "scores_per_step": total_scores, "top_k": top_k, "seed": args.seed,
+            "parallelism": f"paths sharded over {world} GPU(s), RCCL max-all-reduce + top-k all-gather per level",
+        },
+        "roofline": roofline,
+        "kernel_time_frac": null_s / elapsed if elapsed > 0 else None,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(prob, masks)
+        except Exception as e:   # the baseline is reported, never required
+            line["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,7 +33,8 @@ class gcre_result(ctypes.Structure):
 
 
 class gcre_join_opts(ctypes.Structure):
-    _fields_ = [("shard_begin", ctypes.c_int64), ("shard_end", ctypes.c_int64), ("d_null_out", ctypes.c_void_p)]
+    _fields_ = [("sharded", ctypes.c_int32), ("reserved", ctypes.c_int32), ("shard_begin", ctypes.c_int64),
+                ("shard_end", ctypes.c_int64), ("d_null_out", ctypes.c_void_p)]
 
 
 class gcre_profile(ctypes.Structure):
@@ -62,7 +63,8 @@ EXPORTS = [
     "gcre_create", "gcre_destroy", "gcre_last_error", "gcre_abi_version", "gcre_set_top_k", "gcre_width_ul",
     "gcre_vlen", "gcre_set_value_table", "gcre_set_perm_cases", "gcre_set_perm_masks", "gcre_pathset_zeros",
     "gcre_pathset_from_dense", "gcre_pathset_from_words", "gcre_pathset_select", "gcre_pathset_size",
-    "gcre_pathset_read", "gcre_pathset_free", "gcre_join", "gcre_result_free", "gcre_get_profile",
+    "gcre_pathset_read", "gcre_pathset_free", "gcre_join", "gcre_result_free", "gcre_uids_create",
+    "gcre_uids_total_paths", "gcre_uids_free", "gcre_join_uids", "gcre_get_profile",
     "gcre_process_paths", "gcre_resolve_count_locs",
 ]
 
@@ -112,6 +114,13 @@ def load_library():
                               ctypes.POINTER(gcre_result)]
     lib.gcre_result_free.argtypes = [ctypes.POINTER(gcre_result)]
     lib.gcre_result_free.restype = None
+    lib.gcre_uids_create.restype = V
+    lib.gcre_uids_create.argtypes = [V, I, P, P, I64, P, I64]
+    lib.gcre_uids_total_paths.restype = I64
+    lib.gcre_uids_total_paths.argtypes = [V]
+    lib.gcre_uids_free.argtypes = [V]
+    lib.gcre_uids_free.restype = None
+    lib.gcre_join_uids.argtypes = [V, V, V, V, V, ctypes.POINTER(gcre_join_opts), ctypes.POINTER(gcre_result)]
     lib.gcre_get_profile.argtypes = [V, ctypes.POINTER(gcre_profile)]
     lib.gcre_process_paths.argtypes = [V, ctypes.POINTER(gcre_pp_input), ctypes.POINTER(gcre_result)]
     lib.gcre_resolve_count_locs.argtypes = [P, I64, P, P, P, I64, P, P]
@@ -191,6 +200,33 @@ class PathSet:
         h, self._h = self._h, None
         if h and self._owner._h:
             self._owner._lib.gcre_pathset_free(h)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceUids:
+    """UidRelSet (src/gcre.h:49-90) resident on the device."""
+
+    def __init__(self, owner: "JoinExec", uids):
+        count = np.ascontiguousarray(uids.count, dtype=np.int32)
+        location = np.ascontiguousarray(uids.location, dtype=np.int64)
+        signs = np.ascontiguousarray(uids.signs, dtype=np.int32)
+        self._owner = owner
+        self.path_length = int(uids.path_length)
+        self._h = owner._lib.gcre_uids_create(owner._h, self.path_length, _ptr(count), _ptr(location), len(count),
+                                              _ptr(signs), len(signs))
+        if not self._h:
+            owner._raise()
+        self.total_paths = int(owner._lib.gcre_uids_total_paths(self._h))
+
+    def free(self) -> None:
+        h, self._h = self._h, None
+        if h and self._owner._h:
+            self._owner._lib.gcre_uids_free(h)
 
     def __del__(self):
         try:
@@ -280,19 +316,25 @@ class JoinExec:
 
     def join(self, uids, paths0: PathSet, paths1: PathSet, paths_res: Optional[PathSet] = None,
              shard: Optional[Tuple[int, int]] = None, d_null_out: int = 0) -> JoinResult:
-        """JoinExec::join (src/join_base.cpp:189-264).  ``paths_res`` receives the joined rows when given."""
-        count = np.ascontiguousarray(uids.count, dtype=np.int32)
-        location = np.ascontiguousarray(uids.location, dtype=np.int64)
-        signs = np.ascontiguousarray(uids.signs, dtype=np.int32)
-        opts = gcre_join_opts(0, 0, None)
+        """JoinExec::join (src/join_base.cpp:189-264).  ``paths_res`` receives the joined rows when given.
+        ``uids`` is a UidRelSet (uploaded for this call) or a DeviceUids (already resident)."""
+        opts = gcre_join_opts(0, 0, 0, 0, None)
         if shard is not None:
-            opts.shard_begin, opts.shard_end = int(shard[0]), int(shard[1])
+            opts.sharded, opts.shard_begin, opts.shard_end = 1, int(shard[0]), int(shard[1])
         if d_null_out:
             opts.d_null_out = ctypes.c_void_p(int(d_null_out))
         res = gcre_result()
-        rc = self._lib.gcre_join(self._h, int(uids.path_length), _ptr(count), _ptr(location), len(count),
-                                 _ptr(signs), len(signs), paths0._h, paths1._h,
-                                 paths_res._h if paths_res is not None else None, ctypes.byref(opts), ctypes.byref(res))
+        res_h = paths_res._h if paths_res is not None else None
+        if isinstance(uids, DeviceUids):
+            rc = self._lib.gcre_join_uids(self._h, uids._h, paths0._h, paths1._h, res_h, ctypes.byref(opts),
+                                          ctypes.byref(res))
+        else:
+            count = np.ascontiguousarray(uids.count, dtype=np.int32)
+            location = np.ascontiguousarray(uids.location, dtype=np.int64)
+            signs = np.ascontiguousarray(uids.signs, dtype=np.int32)
+            rc = self._lib.gcre_join(self._h, int(uids.path_length), _ptr(count), _ptr(location), len(count),
+                                     _ptr(signs), len(signs), paths0._h, paths1._h, res_h, ctypes.byref(opts),
+                                     ctypes.byref(res))
         self._check(rc)
         return _take_result(self._lib, res)
 
@@ -359,3 +401,80 @@ def process_paths(problem, device: int = 0, exec_: Optional[JoinExec] = None) ->
     if exec_ is None:
         ex.close()
     return result
+
+
+class ResidentPlan:
+    """The ProcessPaths join sequence (src/wrapper.cpp:216-276) with every input already in HBM.
+
+    ``prepare`` uploads data, table, masks and the per-level join indices once; ``run`` then performs the
+    joins of one pass: levels 1a, 1b, 2 .. path_length.  With ``world > 1`` each rank scores a contiguous
+    slice of every level's joined paths (kept rows are materialised in full on every rank) and the caller
+    merges null maxima (MAX) and top-k tables across ranks -- see bench.py.
+    """
+
+    LEVELS = ["1a", "1b", "2", "3", "4", "5"]
+
+    def __init__(self, problem, device: int = 0, packed_masks: Optional[np.ndarray] = None):
+        self.problem = problem
+        ex = self.ex = JoinExec(problem.method, problem.n_cases, problem.n_ctrls, problem.iterations, device)
+        ex.top_k = problem.top_k
+        ex.set_value_table(problem.value_table)
+        if packed_masks is not None:
+            ex.set_permuted_masks(packed_masks)
+        else:
+            ex.set_permuted_cases(problem.perm_cases)
+        lv, L = problem.levels, problem.path_length
+        self.names = ["1a", "1b"] + [str(l) for l in range(2, L + 1)]
+        self.uids = {k: DeviceUids(ex, lv.uids[k]) for k in self.names}
+        parsed1 = ex.load(problem.data1)
+        parsed2 = ex.load(problem.data2)
+        self.inputs = {"1a": parsed1.select(lv.data_inds["1a"]), "1b": parsed2.select(lv.data_inds["1b"])}
+        self.zeros = {"1a": ex.create_path_set(len(lv.data_inds["1a"])), "1b": ex.create_path_set(len(lv.data_inds["1b"]))}
+        if L >= 2:
+            self.inputs["2"] = parsed1.select(lv.data_inds["3"])   # wrapper.cpp:207 reads data_idx2 from r_data_inds3
+        if L >= 3:
+            self.inputs["3"] = parsed1.select(lv.data_inds["3"])
+        parsed1.free()
+        parsed2.free()
+        self.kept = {"1": ex.create_path_set(self.uids["1a"].total_paths)}
+        if L >= 2:
+            self.kept["2"] = ex.create_path_set(self.uids["2"].total_paths)
+        if L >= 3:
+            self.kept["3"] = ex.create_path_set(self.uids["3"].total_paths)
+
+    def operands(self, name: str):
+        """(paths0, paths1, paths_res) of one level, as in wrapper.cpp:227-276."""
+        k = self.kept
+        return {
+            "1a": (self.zeros["1a"], self.inputs["1a"], k["1"]),
+            "1b": (self.zeros["1b"], self.inputs["1b"], None),
+            "2": (k["1"], self.inputs.get("2"), k.get("2")),
+            "3": (k.get("2"), self.inputs.get("3"), k.get("3")),
+            "4": (k.get("3"), k.get("2"), None),
+            "5": (k.get("3"), k.get("3"), None),
+        }[name]
+
+    def shard(self, name: str, rank: int, world: int) -> Tuple[int, int]:
+        total = self.uids[name].total_paths
+        return (total * rank) // world, (total * (rank + 1)) // world
+
+    def run(self, rank: int = 0, world: int = 1, d_null_out: int = 0, on_level=None) -> Dict[str, JoinResult]:
+        out: Dict[str, JoinResult] = {}
+        prof: Dict[str, float] = {}
+        for name in self.names:
+            p0, p1, res = self.operands(name)
+            b, e = self.shard(name, rank, world)
+            r = self.ex.join(self.uids[name], p0, p1, res, shard=(b, e) if world > 1 else None, d_null_out=d_null_out)
+            for k, v in self.ex.profile().items():
+                prof[k] = prof.get(k, 0) + v
+            if on_level is not None:
+                r = on_level(name, r, (b, e))
+            out[name] = r
+        self.last_profile = prof
+        return out
+
+    def total_scores(self) -> int:
+        return self.problem.iterations * sum(self.uids[k].total_paths for k in self.names)
+
+    def close(self):
+        self.ex.close()

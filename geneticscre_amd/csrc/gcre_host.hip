@@ -82,8 +82,6 @@ struct gcre_ctx {
   uint32_t* d_null = nullptr;        // [Kpad]
 
   // per-join scratch
-  DevBuf<int64_t> d_path_idx, d_location;
-  DevBuf<int32_t> d_signs;
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
   DevBuf<uint64_t> d_key, d_wkey;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
@@ -97,6 +95,20 @@ struct gcre_pathset {
   gcre_ctx* ctx;
   int64_t nrows;
   uint64_t* d_rows;   // max(nrows,1) x S words
+};
+
+// UidRelSet (src/gcre.h:49-90) resident on the device: prefix sums of count, locations, signs
+struct gcre_uids {
+  gcre_ctx* ctx;
+  int path_length;
+  int64_t n_uids;
+  int64_t n_signs;
+  int64_t total;      // count_total_paths()
+  int64_t max_loc;    // largest paths1 row referenced, -1 if none
+  int64_t max_idx;    // largest uid row with count > 0, -1 if none
+  int64_t* d_path_idx;
+  int64_t* d_location;
+  int32_t* d_signs;
 };
 
 namespace {
@@ -237,18 +249,59 @@ int select_chunk(gcre_ctx* c, int64_t count, int k, uint32_t* n_selected) {
 }
 
 struct JoinPlan {
-  int path_length;
-  const int32_t* uid_count;
-  const int64_t* uid_location;
-  int64_t n_uids;
-  const int32_t* signs;
-  int64_t n_signs;
+  const gcre_uids* u;
   const gcre_pathset* p0;
   const gcre_pathset* p1;
   gcre_pathset* res;
+  bool sharded;
   int64_t shard_begin, shard_end;
   void* d_null_out;
 };
+
+void free_uids(gcre_uids* u) {
+  if (!u) return;
+  if (u->ctx && u->ctx->stream) (void)hipStreamSynchronize(u->ctx->stream);
+  for (void* p : {(void*)u->d_path_idx, (void*)u->d_location, (void*)u->d_signs})
+    if (p) (void)hipFree(p);
+  delete u;
+}
+
+// validation that does not need the path sets (join_base.cpp:198-200 checks the rest in run_join)
+gcre_uids* make_uids(gcre_ctx* c, int path_length, const int32_t* uid_count, const int64_t* uid_location,
+                     int64_t n_uids, const int32_t* signs, int64_t n_signs) {
+  auto* u = new gcre_uids{c, path_length, n_uids, n_signs, 0, -1, -1, nullptr, nullptr, nullptr};
+  std::vector<int64_t> path_idx((size_t)n_uids + 1, 0);
+  for (int64_t i = 0; i < n_uids; i++) {
+    const int cnt = uid_count[i];
+    if (cnt > 0) {
+      const int64_t loc = uid_location[i];
+      if (loc < 0) {
+        fail(c, GCRE_ERR_RANGE, "assertion: uid location out of range");
+        delete u;
+        return nullptr;
+      }
+      u->max_loc = std::max(u->max_loc, loc + cnt - 1);
+      u->max_idx = i;
+    }
+    path_idx[(size_t)i + 1] = path_idx[(size_t)i] + std::max(cnt, 0);   // uid_ref.path_idx, wrapper.cpp:128-130
+  }
+  u->total = path_idx[(size_t)n_uids];
+  hipError_t e = hipMalloc((void**)&u->d_path_idx, path_idx.size() * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&u->d_location, (size_t)std::max<int64_t>(n_uids, 1) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&u->d_signs, (size_t)std::max<int64_t>(n_signs, 1) * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(u->d_path_idx, path_idx.data(), path_idx.size() * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && n_uids > 0)
+    e = hipMemcpyAsync(u->d_location, uid_location, (size_t)n_uids * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && n_signs > 0)
+    e = hipMemcpyAsync(u->d_signs, signs, (size_t)n_signs * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // path_idx is a local
+  if (e != hipSuccess) {
+    fail(c, GCRE_ERR_DEVICE, std::string("uids upload: ") + hipGetErrorString(e));
+    free_uids(u);
+    return nullptr;
+  }
+  return u;
+}
 
 int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   const Geometry& g = c->g;
@@ -257,38 +310,28 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   if (!c->have_table) return fail(c, GCRE_ERR_ASSERT, "value table not set");
   if (g.K > 0 && !c->have_perms) return fail(c, GCRE_ERR_ASSERT, "permuted cases not set");
   if (c->top_k < 1) return fail(c, GCRE_ERR_ARG, "top_k must be >= 1");
-  if (!jp.p0 || !jp.p1 || jp.p0->ctx != c || jp.p1->ctx != c || (jp.res && jp.res->ctx != c))
-    return fail(c, GCRE_ERR_ARG, "path set does not belong to this context");
+  if (!jp.u || jp.u->ctx != c || !jp.p0 || !jp.p1 || jp.p0->ctx != c || jp.p1->ctx != c || (jp.res && jp.res->ctx != c))
+    return fail(c, GCRE_ERR_ARG, "uids / path set do not belong to this context");
+  const gcre_uids& u = *jp.u;
 
   // ---- the checks of JoinExec::join, join_base.cpp:196-200 ----
-  if (jp.n_uids != jp.p0->nrows) return fail(c, GCRE_ERR_ASSERT, "assertion: uids.size() != paths0.size");
-  std::vector<int64_t> path_idx((size_t)jp.n_uids + 1, 0);
-  int64_t max_loc = -1, max_idx = -1;
-  for (int64_t i = 0; i < jp.n_uids; i++) {
-    const int cnt = jp.uid_count[i];
-    if (cnt > 0) {
-      const int64_t loc = jp.uid_location[i];
-      if (loc < 0 || loc + cnt - 1 >= jp.p1->nrows) return fail(c, GCRE_ERR_RANGE, "assertion: uid location out of range");
-      max_loc = std::max(max_loc, loc + cnt - 1);
-      max_idx = i;
-    }
-    path_idx[(size_t)i + 1] = path_idx[(size_t)i] + std::max(cnt, 0);   // uid_ref.path_idx, wrapper.cpp:128-130
-  }
-  const int64_t P = path_idx[(size_t)jp.n_uids];
+  if (u.n_uids != jp.p0->nrows) return fail(c, GCRE_ERR_ASSERT, "assertion: uids.size() != paths0.size");
+  if (u.max_loc >= jp.p1->nrows) return fail(c, GCRE_ERR_RANGE, "assertion: uid location out of range");
+  const int64_t P = u.total;
   const bool keep = jp.res != nullptr && jp.res->nrows != 0;   // keep_paths = paths_res.size != 0, join_base.cpp:217
   if (jp.res && jp.res->nrows != 0 && jp.res->nrows != P)
     return fail(c, GCRE_ERR_ASSERT, "assertion: paths_res.size != total paths");
   if (g.method == 2 && P > 0) {
     // need_flip reads signs[idx] and/or signs[loc] (gcre.h:71-81); the reference would read out of bounds
     int64_t need_signs = 0;
-    if (jp.path_length > 3) need_signs = max_idx + 1;
-    else if (jp.path_length < 3) need_signs = max_loc + 1;
-    else need_signs = std::max(max_idx, max_loc) + 1;
-    if (jp.n_signs < need_signs) return fail(c, GCRE_ERR_RANGE, "signs vector shorter than the rows it is indexed by");
+    if (u.path_length > 3) need_signs = u.max_idx + 1;
+    else if (u.path_length < 3) need_signs = u.max_loc + 1;
+    else need_signs = std::max(u.max_idx, u.max_loc) + 1;
+    if (u.n_signs < need_signs) return fail(c, GCRE_ERR_RANGE, "signs vector shorter than the rows it is indexed by");
   }
 
   int64_t sb = jp.shard_begin, se = jp.shard_end;
-  if (se <= 0) { sb = 0; se = P; }
+  if (!jp.sharded) { sb = 0; se = P; }
   sb = std::max<int64_t>(0, std::min(sb, P));
   se = std::max(sb, std::min(se, P));
 
@@ -302,16 +345,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   double select_ms = 0;
 
   if (P > 0) {
-    HIP_TRY(c, c->d_path_idx.reserve(path_idx.size()));
-    HIP_TRY(c, c->d_location.reserve((size_t)jp.n_uids));
-    HIP_TRY(c, hipMemcpyAsync(c->d_path_idx.p, path_idx.data(), path_idx.size() * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_location.p, jp.uid_location, (size_t)jp.n_uids * 8, hipMemcpyHostToDevice, st));
-    if (g.method == 2) {
-      HIP_TRY(c, c->d_signs.reserve((size_t)std::max<int64_t>(jp.n_signs, 1)));
-      if (jp.n_signs > 0)
-        HIP_TRY(c, hipMemcpyAsync(c->d_signs.p, jp.signs, (size_t)jp.n_signs * 4, hipMemcpyHostToDevice, st));
-    }
-
     // segments: rows outside the shard are only materialised (when kept); the shard is scored
     struct Seg { int64_t b, e; bool score; };
     std::vector<Seg> segs;
@@ -342,7 +375,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         }
         hipEvent_t e0 = get_event(c), e1 = get_event(c);
         HIP_TRY(c, hipEventRecord(e0, st));
-        HIP_TRY(c, launch_expand(c->d_path_idx.p, c->d_location.p, jp.n_uids, c->d_signs.p, jp.path_length, g.method,
+        HIP_TRY(c, launch_expand(u.d_path_idx, u.d_location, u.n_uids, u.d_signs, u.path_length, g.method,
                                  cb, n, c->d_row0.p, c->d_row1.p, st));
         StatsArgs sa{};
         sa.p0 = jp.p0->d_rows;
@@ -561,9 +594,6 @@ void gcre_destroy(gcre_ctx* c) {
   for (void* p : {(void*)c->d_case_mask, (void*)c->d_masks, (void*)c->d_t32, (void*)c->d_dvt, (void*)c->d_dmax,
                   (void*)c->d_null})
     if (p) (void)hipFree(p);
-  c->d_path_idx.release();
-  c->d_location.release();
-  c->d_signs.release();
   for (auto* b : {&c->d_row0, &c->d_row1, &c->d_tot, &c->d_cases, &c->d_ctrls, &c->d_sel, &c->d_small, &c->d_chunk,
                   &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})
     b->release();
@@ -800,8 +830,39 @@ int gcre_join(gcre_ctx* c, int path_length, const int32_t* uid_count, const int6
       (n_signs > 0 && !signs))
     return fail(c, GCRE_ERR_ARG, "bad join arguments");
   (void)hipSetDevice(c->device);
-  JoinPlan jp{path_length, uid_count, uid_location, n_uids, signs, n_signs, paths0, paths1, res,
-              opts ? opts->shard_begin : 0, opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
+  gcre_uids* u = make_uids(c, path_length, uid_count, uid_location, n_uids, signs, n_signs);
+  if (!u) return c->last_code;
+  JoinPlan jp{u, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
+              opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
+  int rc = run_join(c, jp, out);
+  free_uids(u);
+  if (rc != GCRE_OK) gcre_result_free(out);
+  return rc;
+}
+
+gcre_uids* gcre_uids_create(gcre_ctx* c, int path_length, const int32_t* uid_count, const int64_t* uid_location,
+                            int64_t n_uids, const int32_t* signs, int64_t n_signs) {
+  if (!c || n_uids < 0 || (n_uids > 0 && (!uid_count || !uid_location)) || n_signs < 0 || (n_signs > 0 && !signs)) {
+    fail(c, GCRE_ERR_ARG, "bad uids arguments");
+    return nullptr;
+  }
+  (void)hipSetDevice(c->device);
+  return make_uids(c, path_length, uid_count, uid_location, n_uids, signs, n_signs);
+}
+
+int64_t gcre_uids_total_paths(const gcre_uids* u) { return u ? u->total : GCRE_ERR_ARG; }
+
+void gcre_uids_free(gcre_uids* u) {
+  if (u && u->ctx) (void)hipSetDevice(u->ctx->device);
+  free_uids(u);
+}
+
+int gcre_join_uids(gcre_ctx* c, const gcre_uids* uids, const gcre_pathset* paths0, const gcre_pathset* paths1,
+                   gcre_pathset* res, const gcre_join_opts* opts, gcre_result* out) {
+  if (!c || !uids || !out) return fail(c, GCRE_ERR_ARG, "bad join arguments");
+  (void)hipSetDevice(c->device);
+  JoinPlan jp{uids, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
+              opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
   int rc = run_join(c, jp, out);
   if (rc != GCRE_OK) gcre_result_free(out);
   return rc;
@@ -878,9 +939,12 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
   };
   auto join = [&](int plen, const gcre_level& lv, const gcre_pathset* p0, const gcre_pathset* p1, gcre_pathset* res,
                   gcre_result* o) -> int {
-    JoinPlan jp{plen, lv.uid_count, lv.uid_location, lv.n_uids, lv.signs, lv.n_signs, p0, p1, res, 0, 0, nullptr};
+    gcre_uids* u = make_uids(c, plen, lv.uid_count, lv.uid_location, lv.n_uids, lv.signs, lv.n_signs);
+    if (!u) return c->last_code;
+    JoinPlan jp{u, p0, p1, res, false, 0, 0, nullptr};
     gcre_result tmp;
     int r = run_join(c, jp, &tmp);
+    free_uids(u);
     if (r != GCRE_OK) { gcre_result_free(&tmp); return r; }
     add_prof();
     if (o) *o = tmp; else gcre_result_free(&tmp);

@@ -148,3 +148,31 @@ def make_problem(n_genes: int, n_edges: int, n_cases: int, n_ctrls: int, n_perm:
     vt = values_table(n_cases, n_ctrls) if table is None else table
     perms = case_or_control(n_cases, n_ctrls, n_perm, rng) if n_perm > 0 else np.zeros((0, 0), np.int32)
     return Problem(method, n_cases, n_ctrls, path_length, top_k, n_perm, levels, data1, data2, vt, perms, seed)
+
+
+def packed_case_masks(n_cases: int, n_ctrls: int, n_perm: int, rng: np.random.Generator) -> np.ndarray:
+    """uint64 [n_perm][ceil(n/64)]: bit c of row r = patient c is a case under permutation r.
+
+    Exactly what setPermutedCases derives from ``case_or_control`` (join_base.cpp:85-125: case_mask XOR flipped),
+    without materialising the K x n int matrix -- mask bit c = (perm[c] < n_cases).
+    """
+    n = n_cases + n_ctrls
+    W = (n + 63) // 64
+    out = np.zeros((n_perm, W), dtype=np.uint64)
+    weights = (np.uint64(1) << np.arange(64, dtype=np.uint64))
+    for r in range(n_perm):
+        bits = np.zeros(W * 64, dtype=np.uint64)
+        bits[:n] = rng.permutation(n) < n_cases
+        out[r] = (bits.reshape(W, 64) * weights).sum(axis=1, dtype=np.uint64)
+    return out
+
+
+def masks_from_case_or_control(perm_cases: np.ndarray, n_cases: int) -> np.ndarray:
+    """Pack a K x n "label kept" matrix (Utils.R:246-262) the way setPermutedCases does (join_base.cpp:97-111)."""
+    K, n = perm_cases.shape
+    W = (n + 63) // 64
+    is_case = np.arange(n) < n_cases
+    bits = np.zeros((K, W * 64), dtype=np.uint64)
+    bits[:, :n] = is_case[None, :] ^ (perm_cases != 1)
+    weights = (np.uint64(1) << np.arange(64, dtype=np.uint64))
+    return (bits.reshape(K, W, 64) * weights).sum(axis=2, dtype=np.uint64)

@@ -51,8 +51,10 @@ typedef struct {
 
 /* Optional knobs of one join.  Zero-initialise for the reference behaviour. */
 typedef struct {
-  int64_t shard_begin;  /* joined-path ordinal range scored on THIS device: [shard_begin, shard_end). */
-  int64_t shard_end;    /* shard_end <= 0 means "all paths".  Kept path rows are always produced in full. */
+  int32_t sharded;      /* 0: score every joined path (reference behaviour); 1: only [shard_begin, shard_end) */
+  int32_t reserved;
+  int64_t shard_begin;  /* joined-path ordinal range scored on THIS device (may be empty). */
+  int64_t shard_end;    /* Kept path rows are always produced in full, whatever the shard. */
   void* d_null_out;     /* optional device pointer to iterations floats: receives this shard's null maxima
                            (for an RCCL MAX all-reduce by the caller); may be NULL */
 } gcre_join_opts;
@@ -113,6 +115,16 @@ int gcre_join(gcre_ctx* ctx, int path_length,
               const gcre_pathset* paths0, const gcre_pathset* paths1, gcre_pathset* res,
               const gcre_join_opts* opts, gcre_result* out);
 void gcre_result_free(gcre_result* r);
+
+/* UidRelSet (src/gcre.h:49-90) kept resident on the device, for callers that join the same level repeatedly
+ * (benchmarks, sharded runs): gcre_join_uids == gcre_join without re-uploading the index. */
+typedef struct gcre_uids gcre_uids;
+gcre_uids* gcre_uids_create(gcre_ctx* ctx, int path_length, const int32_t* uid_count, const int64_t* uid_location,
+                            int64_t n_uids, const int32_t* signs, int64_t n_signs);
+int64_t gcre_uids_total_paths(const gcre_uids* uids);   /* UidRelSet::count_total_paths, gcre.h:83-88 */
+void gcre_uids_free(gcre_uids* uids);
+int gcre_join_uids(gcre_ctx* ctx, const gcre_uids* uids, const gcre_pathset* paths0, const gcre_pathset* paths1,
+                   gcre_pathset* res, const gcre_join_opts* opts, gcre_result* out);
 
 int gcre_get_profile(const gcre_ctx* ctx, gcre_profile* out);
 

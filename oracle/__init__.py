@@ -67,6 +67,7 @@ def _lib():
     lib.gcre_o_vlen.argtypes = [P]
     lib.gcre_o_set_value_table.argtypes = [P, P, c_i, c_i]
     lib.gcre_o_set_perm_cases.argtypes = [P, P, c_i, c_i]
+    lib.gcre_o_set_perm_masks.argtypes = [P, P, c_i]
     lib.gcre_o_get_perm_mask.argtypes = [P, c_i, P]
     lib.gcre_o_pack_dense.argtypes = [P, P, c_i, c_i, P]
     lib.gcre_o_join.argtypes = [P, c_i, P, P, c_i64, P, c_i64, P, c_i64, P, c_i64, P,
@@ -124,6 +125,11 @@ class OracleJoinExec:
         if p.ndim != 2:
             p = p.reshape(0, 0)
         _check(_lib().gcre_o_set_perm_cases(self._h, _ptr(p), p.shape[0], p.shape[1]))
+
+    def set_packed_masks(self, masks) -> None:
+        """Masks already packed (uint64 [rows][width]); same reuse / truncation rules as set_permuted_cases."""
+        m = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, self.width)
+        _check(_lib().gcre_o_set_perm_masks(self._h, _ptr(m), m.shape[0]))
 
     def perm_mask(self, r: int) -> np.ndarray:
         out = np.zeros(self.width, dtype=np.uint64)

@@ -111,6 +111,19 @@ int gcre_o_set_perm_cases(gcre_o_ctx* c, const int* perms, int nrow, int ncol) {
   return 0;
 }
 
+int gcre_o_set_perm_masks(gcre_o_ctx* c, const uint64_t* masks, int nrow) {
+  // the masks setPermutedCases would derive, supplied packed: [nrow][width]
+  const int K = c->iters, W = c->width;
+  std::fill(c->perm_mask.begin(), c->perm_mask.end(), 0);
+  if (K > 0 && nrow <= 0) return -1;
+  for (int r = 0; r < K; r++) {
+    const int s = r % nrow;
+    for (int k = 0; k < W; k++) c->perm_mask[size_t(k) * K + r] = masks[size_t(s) * W + k];
+  }
+  c->have_perms = true;
+  return 0;
+}
+
 int gcre_o_get_perm_mask(const gcre_o_ctx* c, int r, uint64_t* out) {
   if (r < 0 || r >= c->iters) return -2;
   for (int k = 0; k < c->width; k++) out[k] = c->perm_mask[size_t(k) * c->iters + r];

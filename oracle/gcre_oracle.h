@@ -38,6 +38,9 @@ int gcre_o_set_value_table(gcre_o_ctx* ctx, const double* tbl, int nrow, int nco
 /* JoinExec::setPermutedCases -- src/join_base.cpp:85-125.  perms row-major nrow x ncol, 1 = label kept. */
 int gcre_o_set_perm_cases(gcre_o_ctx* ctx, const int* perms, int nrow, int ncol);
 
+/* the same masks supplied already packed: nrow x width words, bit c = patient c is a case under permutation r */
+int gcre_o_set_perm_masks(gcre_o_ctx* ctx, const uint64_t* masks, int nrow);
+
 /* read back permutation mask r as width words (test hook) */
 int gcre_o_get_perm_mask(const gcre_o_ctx* ctx, int r, uint64_t* out);
 
