@@ -52,15 +52,21 @@ def build_inputs(cfg, seed, top_k):
     return prob, masks
 
 
-def merge_topk(rows: np.ndarray, top_k: int) -> np.ndarray:
-    """rows [m, 5] = (score, src, trg, cases, ctrls) gathered from all ranks -> the reference's result table:
-    best top_k of {sentinel} U rows, ascending, ties to the smaller (src, trg) = smaller joined-path ordinal."""
-    rows = rows[rows[:, 1] >= 0]                                    # drop every rank's sentinel / padding
-    order = np.lexsort((rows[:, 2], rows[:, 1], -rows[:, 0]))       # score desc, src asc, trg asc
-    best = rows[order[:top_k]]
-    if len(best) < top_k:
-        best = np.vstack([best, [[-np.inf, -1, -1, 0, 0]]])
-    return best[::-1]
+def host_threads() -> int:
+    """CPU threads this process may actually use: the cgroup quota on the GPU box (16 for a 1-GPU share),
+    the affinity mask, or the core count -- whichever is smallest."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(prob, masks, budget_s=15.0):
@@ -68,7 +74,7 @@ def cpu_baseline(prob, masks, budget_s=15.0):
     workload: a prefix of the deepest level's join index, all K permutations, all host cores."""
     import oracle
     from geneticscre_amd.uids import UidRelSet
-    threads = os.cpu_count() or 1
+    threads = host_threads()
     ex = oracle.OracleJoinExec(prob.method, prob.n_cases, prob.n_ctrls, prob.iterations)
     ex.top_k, ex.nthreads = prob.top_k, threads
     ex.set_value_table(prob.value_table)
@@ -148,6 +154,7 @@ def main():
     prob, masks = build_inputs(cfg, args.seed, args.top_k)
 
     from geneticscre_amd import api
+    from geneticscre_amd.dist import exchange_level
     plan = api.ResidentPlan(prob, device=local_rank, packed_masks=masks)
     K, top_k = prob.iterations, prob.top_k
     d_null = torch.zeros(max(K, 1), dtype=torch.float32, device=dev)
@@ -156,20 +163,10 @@ def main():
     def on_level(name, r, shard):
         if world == 1:
             return r
-        # RCCL: element-wise MAX of the f32 null maxima (exact: max is associative, App. A-7) ...
-        dist.all_reduce(d_null, op=dist.ReduceOp.MAX)
-        # ... and an all-gather of every rank's top-k table, merged identically on all ranks
-        mine = torch.full((top_k + 1, 5), -1.0, dtype=torch.float64)
-        mine[:, 0] = float("-inf")
-        rows = np.stack([r.scores, r.src, r.trg, r.cases, r.ctrls], axis=1)
-        mine[: len(rows)] = torch.from_numpy(rows)
-        mine = mine.to(dev)
-        allrows = torch.empty((world * (top_k + 1), 5), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allrows, mine)
-        best = merge_topk(allrows.cpu().numpy(), top_k)
+        # RCCL: MAX all-reduce of the null maxima + all-gather/merge of the top-k tables (geneticscre_amd/dist.py)
+        best = exchange_level(r.scores, r.src, r.trg, r.cases, r.ctrls, d_null, top_k, world, device=dev)
         return api.JoinResult(best[:, 0].copy(), best[:, 1].astype(np.int32), best[:, 2].astype(np.int32),
-                              best[:, 3].astype(np.int32), best[:, 4].astype(np.int32),
-                              d_null[:K].cpu().numpy())
+                              best[:, 3].astype(np.int32), best[:, 4].astype(np.int32), d_null[:K].cpu().numpy())
 
     def step():
         out = plan.run(rank, world, d_null_out=d_null.data_ptr(), on_level=on_level)

@@ -1,0 +1,155 @@
+"""JoinExec / PathSet level tests of the HIP library against the oracle (pytest -m gpu, real MI355X)."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from geneticscre_amd import api, dist, synth
+from geneticscre_amd.synth import make_problem
+from helpers import assert_same_result, small_table
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(p):
+    ex = api.JoinExec(p.method, p.n_cases, p.n_ctrls, p.iterations)
+    ex.top_k = p.top_k
+    ex.set_value_table(p.value_table)
+    ex.set_permuted_cases(p.perm_cases)
+    ox = oracle.OracleJoinExec(p.method, p.n_cases, p.n_ctrls, p.iterations)
+    ox.top_k = p.top_k
+    ox.set_value_table(p.value_table)
+    ox.set_permuted_cases(p.perm_cases)
+    return ex, ox
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_load_select_and_kept_rows_round_trip(method):
+    """PathSet::load / select (gcre_paths.h:56-92) and the rows a keep-join writes (join_base.cpp:243-249)."""
+    p = make_problem(35, 80, 70, 61, 20, 3, method=method, top_k=6, seed=21, table=small_table(70, 61, 5))
+    ex, ox = make_pair(p)
+    d = ex.load(p.data1)
+    want = ox.load(p.data1)
+    np.testing.assert_array_equal(d.to_numpy(), want)
+    idx = p.levels.data_inds["3"]
+    np.testing.assert_array_equal(d.select(idx).to_numpy(), want[idx])
+    np.testing.assert_array_equal(ex.from_words(want).to_numpy(), want)
+    # keep joins of levels 1a -> 2 -> 3: rows must be bit-identical, including the (+)/(-) halves of method 2
+    lv = p.levels
+    full = oracle.process_paths(p, order="canonical")
+    z = ex.create_path_set(len(lv.data_inds["1a"]))
+    k1 = ex.create_path_set(lv.n_paths["1a"])
+    ex.join(lv.uids["1a"], z, d.select(lv.data_inds["1a"]), k1)
+    np.testing.assert_array_equal(k1.to_numpy(), full["paths1"])
+    k2 = ex.create_path_set(lv.n_paths["2"])
+    r2 = ex.join(lv.uids["2"], k1, d.select(lv.data_inds["2"]), k2)
+    np.testing.assert_array_equal(k2.to_numpy(), full["paths2"])
+    assert_same_result(r2, full["lst2"])
+    k3 = ex.create_path_set(lv.n_paths["3"])
+    r3 = ex.join(lv.uids["3"], k2, d.select(lv.data_inds["3"]), k3)
+    np.testing.assert_array_equal(k3.to_numpy(), full["paths3"])
+    assert_same_result(r3, full["lst3"])
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_shards_and_chunks_reproduce_the_full_join(method, monkeypatch):
+    """Scoring a level in 3 shards, with the device chunk forced down to 64 paths, then merging the way bench.py
+    does (MAX of null maxima, top-k merge) equals the one-shot result -- ids included."""
+    monkeypatch.setenv("GCRE_CHUNK_PATHS", "64")
+    p = make_problem(45, 130, 33, 48, 150, 4, method=method, top_k=10, seed=31, table=small_table(33, 48, 6))
+    ex, ox = make_pair(p)
+    full = oracle.process_paths(p, order="canonical")
+    p3, p2 = ex.from_words(full["paths3"]), ex.from_words(full["paths2"])
+    u = p.levels.uids["4"]
+    du = api.DeviceUids(ex, u)
+    whole = ex.join(du, p3, p2)
+    assert_same_result(whole, full["lst4"])
+    total = du.total_paths
+    null = np.zeros(p.iterations, np.float32)
+    rows = []
+    for r in range(3):
+        b, e = dist.shard_bounds(total, r, 3)
+        part = ex.join(du, p3, p2, shard=(b, e))
+        null = np.maximum(null, part.null)
+        rows.append(np.stack([part.scores, part.src, part.trg, part.cases, part.ctrls], axis=1))
+    best = dist.merge_topk(np.vstack(rows), p.top_k)
+    np.testing.assert_array_equal(best[:, 0], full["lst4"].scores)
+    np.testing.assert_array_equal(best[:, 1], full["lst4"].src)
+    np.testing.assert_array_equal(best[:, 2], full["lst4"].trg)
+    np.testing.assert_array_equal(null.view(np.uint32), full["lst4"].null.view(np.uint32))
+    empty = ex.join(du, p3, p2, shard=(5, 5))     # an empty shard is legal: sentinel only, null maxima all zero
+    assert empty.scores.tolist() == [-math.inf] and not empty.null.any()
+
+
+def test_massive_ties_cut_in_path_order():
+    """Every path scores the same: the selected top-k must be the k smallest joined-path ordinals."""
+    p = make_problem(60, 200, 16, 16, 10, 4, method="method1", top_k=37, seed=41, table=np.full((17, 17), 2.5))
+    got = api.process_paths(p)
+    want = oracle.process_paths(p, order="canonical")
+    for lvl in (2, 3, 4):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+    assert p.levels.n_paths["4"] > 2000      # the tie cut really spans several 1024-entry chunks
+
+
+def test_sentinel_zero_permutations_and_row_reuse():
+    """top_k above the path count -> sentinel (App. A-8); iterations = 0 -> empty TestScores (App. A-3);
+    fewer permutation rows than iterations -> cyclic reuse, more -> truncation (join_base.cpp:89-123)."""
+    p = make_problem(12, 20, 9, 9, 0, 3, method="method1", top_k=400, seed=51, table=small_table(9, 9))
+    got, want = api.process_paths(p), oracle.process_paths(p, order="canonical")
+    for lvl in (1, 2, 3):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+        assert got[f"lst{lvl}"].scores[0] == -math.inf and len(got[f"lst{lvl}"].null) == 0
+        assert np.isnan(got[f"lst{lvl}"].pvalues()).all()        # 0/0 in R, ProcessPaths.R:316
+    q = make_problem(12, 20, 9, 9, 4, 3, method="method2", top_k=5, seed=52, table=small_table(9, 9))
+    for iters in (9, 2):
+        q.iterations = iters
+        got, want = api.process_paths(q), oracle.process_paths(q, order="canonical")
+        for lvl in (1, 2, 3):
+            assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+
+
+def test_packed_masks_equal_int_matrix():
+    p = make_problem(25, 60, 40, 45, 90, 3, method="method1", top_k=4, seed=61, table=small_table(40, 45))
+    a = api.ResidentPlan(p).run()
+    b = api.ResidentPlan(p, packed_masks=synth.masks_from_case_or_control(p.perm_cases, p.n_cases)).run()
+    for k in a:
+        np.testing.assert_array_equal(a[k].null.view(np.uint32), b[k].null.view(np.uint32))
+        np.testing.assert_array_equal(a[k].scores, b[k].scores)
+
+
+def test_reference_assertions_surface_as_errors():
+    """check_equal / check_index / check_true of the reference (gcre_types.h:58-76) become ValueError / IndexError."""
+    p = make_problem(10, 20, 6, 6, 2, 2, seed=2, table=small_table(6, 6))
+    ex, _ = make_pair(p)
+    data = ex.load(p.data1)
+    u = p.levels.uids["2"]
+    with pytest.raises(ValueError):
+        ex.join(u, data.select(np.arange(data.size - 1)), data.select(p.levels.data_inds["2"]))   # uids.size() != paths0.size
+    with pytest.raises(IndexError):
+        ex.join(u, data, data.select(p.levels.data_inds["2"][:-1]))                                # location out of range
+    with pytest.raises(ValueError):
+        ex.join(u, data, data.select(p.levels.data_inds["2"]), ex.create_path_set(3))              # paths_res.size mismatch
+    with pytest.raises(IndexError):
+        data.select([0, data.size])                                                                # PathSet::select check_index
+    with pytest.raises(ValueError):
+        api.JoinExec("method1", 4, 0, 1)                                                           # check_true(num_ctrls > 0)
+    with pytest.raises(ValueError):
+        ex.set_permuted_cases(p.perm_cases[:, :5])                                                 # check_equal on columns
+    fresh = api.JoinExec("method1", 6, 6, 2)
+    with pytest.raises(ValueError):
+        fresh.join(u, fresh.create_path_set(len(u)), fresh.create_path_set(30))                    # table / masks not set
+
+
+def test_r_list_shape_and_pvalues():
+    """make_score_list (wrapper.cpp:142-174): ids are 1-based (idx+1, loc+1); p-value = #(TestScores >= score)/K with
+    the f64 score compared against f32-rounded maxima (ProcessPaths.R:316)."""
+    p = make_problem(30, 70, 20, 20, 50, 3, method="method1", top_k=5, seed=71)
+    r = api.process_paths(p)["lst3"]
+    lst = r.as_r_list()
+    assert lst["ids"].shape == (5, 2) and (lst["ids"][:, 0] == r.src + 1).all()
+    assert lst["debug"][0] == f"[debug] {r.src[0]}:{r.trg[0]} {r.cases[0]}/{r.ctrls[0]}"
+    pv = r.pvalues()
+    want = [(r.null.astype(np.float64) >= s).mean() for s in r.scores]
+    np.testing.assert_array_equal(pv, np.array(want))
+    assert (np.diff(r.scores) >= 0).all()

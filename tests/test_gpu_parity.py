@@ -56,3 +56,42 @@ def test_wide_masks_and_hypergeometric_table(method):
     got, want = run_both(p)
     for lvl in range(1, 5):
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+
+
+@pytest.mark.parametrize("method,n_perm", [("method1", 1100), ("method2", 600)])
+def test_baseline_mask_width_full_parity(method, n_perm):
+    """BASELINE configs[2] geometry (5,000 patients = 79 mask words, real -log hypergeometric table, K not a
+    multiple of the permutation tile) on a network small enough for the oracle: every level bit-exact."""
+    p = make_problem(220, 800, 2500, 2500, n_perm, 4, method=method, top_k=50, seed=77)
+    want = oracle.process_paths(p, order="canonical", nthreads=8)
+    got = api.process_paths(p)
+    for lvl in range(1, 5):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+    assert p.levels.n_paths["4"] > 5000
+
+
+def test_full_size_properties_without_oracle():
+    """At a size the oracle cannot finish in seconds, size-independent properties: (a) null maxima of the whole level
+    equal the element-wise MAX over any partition of it, (b) top-k of the whole equals the merge of the parts,
+    (c) p-values are monotone in the score, (d) a second run is bit-identical (no atomics-order dependence)."""
+    from geneticscre_amd import dist
+    p = make_problem(3000, 30000, 2500, 2500, 2000, 4, method="method1", top_k=64, seed=99)
+    plan = api.ResidentPlan(p)
+    a = plan.run()
+    b = plan.run()
+    for k in a:
+        np.testing.assert_array_equal(a[k].null.view(np.uint32), b[k].null.view(np.uint32))
+        np.testing.assert_array_equal(a[k].scores, b[k].scores)
+        np.testing.assert_array_equal(a[k].src, b[k].src)
+    parts = [plan.run(rank=r, world=4) for r in range(4)]
+    for k in a:
+        null = np.maximum.reduce([q[k].null for q in parts])
+        np.testing.assert_array_equal(null.view(np.uint32), a[k].null.view(np.uint32))
+        rows = np.vstack([np.stack([q[k].scores, q[k].src, q[k].trg, q[k].cases, q[k].ctrls], axis=1) for q in parts])
+        best = dist.merge_topk(rows, p.top_k)
+        np.testing.assert_array_equal(best[:, 0], a[k].scores)
+        np.testing.assert_array_equal(best[:, 1], a[k].src)
+        np.testing.assert_array_equal(best[:, 2], a[k].trg)
+        pv = a[k].pvalues()
+        assert (np.diff(pv) <= 0).all()        # ascending scores -> non-increasing p-values
+    assert plan.uids["4"].total_paths > 200000
