@@ -1,0 +1,263 @@
+/*
+ * r_shim.c -- replacement for the reference's src/wrapper.cpp + src/RcppExports.cpp: a thin .Call shim
+ * that unmarshals the SEXPs, dlopen()s libgcre_hip.so and forwards to the C ABI of include/gcre_hip.h.
+ *
+ * Built INSIDE the R package in place of the Rcpp sources:
+ *     R CMD SHLIB -o geneticsCRE.so r_shim.c -ldl
+ * It needs only R's own C API (no Rcpp).  R is not installed in the build container of this repository, so
+ * this file is compile-untested there; it is deliberately plain C with no logic beyond marshalling.
+ *
+ * Exported registration (identical to reference src/RcppExports.cpp:85-95):
+ *     _geneticsCRE_getRels3 (4 args), _geneticsCRE_getMatchingList (3), _geneticsCRE_ProcessPaths (39)
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gcre_hip.h"
+
+/* ---- the C ABI, resolved at first use ---------------------------------------------------------- */
+static struct {
+  void* handle;
+  gcre_ctx* (*create)(int, int, int, int, int);
+  void (*destroy)(gcre_ctx*);
+  const char* (*last_error)(const gcre_ctx*);
+  int (*set_top_k)(gcre_ctx*, int);
+  int (*process_paths)(gcre_ctx*, const gcre_pp_input*, gcre_result[5]);
+  void (*result_free)(gcre_result*);
+  int (*resolve)(const int32_t*, int64_t, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t*, int64_t*);
+} G;
+
+static void load_abi(void) {
+  if (G.handle) return;
+  const char* path = getenv("GCRE_HIP_LIB");           /* default: next to the package's shared object */
+  if (!path) path = "libgcre_hip.so";
+  G.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!G.handle) Rf_error("geneticsCRE: cannot load %s: %s", path, dlerror());
+#define SYM(field, name)                                             \
+  do {                                                               \
+    *(void**)(&G.field) = dlsym(G.handle, name);                     \
+    if (!G.field) Rf_error("geneticsCRE: %s lacks %s", path, name);  \
+  } while (0)
+  SYM(create, "gcre_create");
+  SYM(destroy, "gcre_destroy");
+  SYM(last_error, "gcre_last_error");
+  SYM(set_top_k, "gcre_set_top_k");
+  SYM(process_paths, "gcre_process_paths");
+  SYM(result_free, "gcre_result_free");
+  SYM(resolve, "gcre_resolve_count_locs");
+#undef SYM
+}
+
+/* named list "uid" -> c(count, location)  ==>  parallel key/count/location arrays (wrapper.cpp:106-112) */
+static void flatten_count_locs(SEXP lst, int32_t** keys, int32_t** counts, int32_t** locs, R_xlen_t* n) {
+  SEXP names = Rf_getAttrib(lst, R_NamesSymbol);
+  *n = XLENGTH(lst);
+  *keys = (int32_t*)R_alloc(*n ? *n : 1, sizeof(int32_t));
+  *counts = (int32_t*)R_alloc(*n ? *n : 1, sizeof(int32_t));
+  *locs = (int32_t*)R_alloc(*n ? *n : 1, sizeof(int32_t));
+  for (R_xlen_t i = 0; i < *n; i++) {
+    SEXP cl = VECTOR_ELT(lst, i);
+    (*keys)[i] = atoi(CHAR(STRING_ELT(names, i)));      /* stoi(uid), wrapper.cpp:111 */
+    (*counts)[i] = INTEGER(cl)[0];
+    (*locs)[i] = INTEGER(cl)[1];
+  }
+}
+
+/* assemble_uids (wrapper.cpp:99-140) for one level */
+static void fill_level(gcre_level* lv, SEXP trg_uids, SEXP count_locs, SEXP signs) {
+  int32_t *keys, *counts, *locs;
+  R_xlen_t nk, n = XLENGTH(trg_uids);
+  flatten_count_locs(count_locs, &keys, &counts, &locs, &nk);
+  int32_t* oc = (int32_t*)R_alloc(n ? n : 1, sizeof(int32_t));
+  int64_t* ol = (int64_t*)R_alloc(n ? n : 1, sizeof(int64_t));
+  if (G.resolve(INTEGER(trg_uids), n, keys, counts, locs, nk, oc, ol) != GCRE_OK)
+    Rf_error("geneticsCRE: gcre_resolve_count_locs failed");
+  lv->uid_count = oc;
+  lv->uid_location = ol;
+  lv->n_uids = n;
+  lv->signs = INTEGER(signs);
+  lv->n_signs = XLENGTH(signs);
+}
+
+/* make_score_list (wrapper.cpp:142-174) */
+static SEXP score_list(const gcre_result* r) {
+  const int m = r->n, K = r->n_perm;
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 6));
+  SEXP nms = PROTECT(Rf_allocVector(STRSXP, 6));
+  static const char* names[6] = {"scores", "ids", "TestScores", "cases", "controls", "debug"};
+  for (int i = 0; i < 6; i++) SET_STRING_ELT(nms, i, Rf_mkChar(names[i]));
+  SEXP scores = PROTECT(Rf_allocVector(REALSXP, m));
+  SEXP ids = PROTECT(Rf_allocMatrix(INTSXP, m, 2));
+  SEXP test = PROTECT(Rf_allocVector(REALSXP, K));
+  SEXP cases = PROTECT(Rf_allocVector(REALSXP, m));
+  SEXP ctrls = PROTECT(Rf_allocVector(REALSXP, m));
+  SEXP debug = PROTECT(Rf_allocVector(STRSXP, m));
+  for (int k = 0; k < K; k++) REAL(test)[k] = (double)r->null_max[k];   /* f32 maxima widened, wrapper.cpp:146-147 */
+  for (int k = 0; k < m; k++) {
+    char buf[96];
+    REAL(scores)[k] = r->scores[k];
+    INTEGER(ids)[k] = r->src[k] + 1;                    /* 1-based for R, wrapper.cpp:157-159 */
+    INTEGER(ids)[k + m] = r->trg[k] + 1;
+    REAL(cases)[k] = r->cases[k];
+    REAL(ctrls)[k] = r->ctrls[k];
+    snprintf(buf, sizeof buf, "[debug] %d:%d %d/%d", r->src[k], r->trg[k], r->cases[k], r->ctrls[k]);   /* :163 */
+    SET_STRING_ELT(debug, k, Rf_mkChar(buf));
+  }
+  SET_VECTOR_ELT(out, 0, scores);
+  SET_VECTOR_ELT(out, 1, ids);
+  SET_VECTOR_ELT(out, 2, test);
+  SET_VECTOR_ELT(out, 3, cases);
+  SET_VECTOR_ELT(out, 4, ctrls);
+  SET_VECTOR_ELT(out, 5, debug);
+  Rf_setAttrib(out, R_NamesSymbol, nms);
+  UNPROTECT(8);
+  return out;
+}
+
+/* ProcessPaths -- same 39 arguments, same order as src/wrapper.cpp:177-185 / R/RcppExports.R:12-14 */
+SEXP _geneticsCRE_ProcessPaths(
+    SEXP src1, SEXP trg1, SEXP cl1, SEXP sg1, SEXP src1b, SEXP trg1b, SEXP cl1b, SEXP sg1b,
+    SEXP src2, SEXP trg2, SEXP cl2, SEXP sg2, SEXP src3, SEXP trg3, SEXP cl3, SEXP sg3,
+    SEXP src4, SEXP trg4, SEXP cl4, SEXP sg4, SEXP src5, SEXP trg5, SEXP cl5, SEXP sg5,
+    SEXP inds1, SEXP inds1b, SEXP inds2, SEXP inds3, SEXP data1, SEXP data2, SEXP value_table,
+    SEXP num_cases, SEXP num_ctrls, SEXP top_k, SEXP iterations, SEXP perm_cases, SEXP method, SEXP path_length,
+    SEXP nthreads) {
+  (void)src1; (void)src1b; (void)src2; (void)src3; (void)src4; (void)src5; (void)nthreads;
+  load_abi();
+  const int nc = Rf_asInteger(num_cases), nt = Rf_asInteger(num_ctrls), K = Rf_asInteger(iterations);
+  /* "method1" -> 1, anything else -> 2 (JoinExec::to_method, gcre.h:125-133) */
+  const int m = strcmp(CHAR(STRING_ELT(method, 0)), "method1") == 0 ? 1 : 2;
+
+  gcre_pp_input in;
+  memset(&in, 0, sizeof in);
+  fill_level(&in.level[0], trg1, cl1, sg1);
+  fill_level(&in.level[1], trg1b, cl1b, sg1b);
+  fill_level(&in.level[2], trg2, cl2, sg2);
+  fill_level(&in.level[3], trg3, cl3, sg3);
+  fill_level(&in.level[4], trg4, cl4, sg4);
+  fill_level(&in.level[5], trg5, cl5, sg5);
+  SEXP inds[4] = {inds1, inds1b, inds2, inds3};
+  for (int i = 0; i < 4; i++) {
+    in.data_inds[i] = INTEGER(inds[i]);
+    in.n_data_inds[i] = XLENGTH(inds[i]);
+  }
+  in.data1 = INTEGER(data1);
+  in.data1_rows = Rf_nrows(data1);
+  in.data2 = INTEGER(data2);
+  in.data2_rows = Rf_nrows(data2);
+  in.data_col_major = 1;                                /* R matrices are column-major (copy_r, wrapper.cpp:78-96) */
+  in.value_table = REAL(value_table);
+  in.vt_rows = Rf_nrows(value_table);
+  in.vt_cols = Rf_ncols(value_table);
+  in.vt_col_major = 1;
+  in.perm_cases = XLENGTH(perm_cases) ? INTEGER(perm_cases) : NULL;   /* matrix(0,0,0) when n_permutations == 0 */
+  in.perm_rows = XLENGTH(perm_cases) ? Rf_nrows(perm_cases) : 0;
+  in.perm_col_major = 1;
+  in.path_length = Rf_asInteger(path_length);
+
+  gcre_ctx* ctx = G.create(m, nc, nt, K, 0);
+  if (!ctx) Rf_error("geneticsCRE: %s", G.last_error(NULL));
+  gcre_result res[5];
+  int rc = G.set_top_k(ctx, Rf_asInteger(top_k));
+  if (rc == GCRE_OK) rc = G.process_paths(ctx, &in, res);
+  if (rc != GCRE_OK) {                                  /* release native resources BEFORE the longjmp of Rf_error */
+    char msg[512];
+    snprintf(msg, sizeof msg, "%s", G.last_error(ctx));
+    G.destroy(ctx);
+    Rf_error("geneticsCRE: %s", msg);
+  }
+
+  /* list(lst1 = ..., ..., lst5 = ...); levels above path_length stay NULL (wrapper.cpp:223) */
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 5));
+  SEXP nms = PROTECT(Rf_allocVector(STRSXP, 5));
+  static const char* names[5] = {"lst1", "lst2", "lst3", "lst4", "lst5"};
+  for (int i = 0; i < 5; i++) {
+    SET_STRING_ELT(nms, i, Rf_mkChar(names[i]));
+    if (res[i].n >= 0) {
+      SET_VECTOR_ELT(out, i, score_list(&res[i]));
+      G.result_free(&res[i]);
+    }
+  }
+  Rf_setAttrib(out, R_NamesSymbol, nms);
+  G.destroy(ctx);
+  UNPROTECT(2);
+  return out;
+}
+
+/* getMatchingList (wrapper.cpp:60-69): named list uid -> c(count, location) */
+SEXP _geneticsCRE_getMatchingList(SEXP uids, SEXP counts, SEXP location) {
+  const R_xlen_t n = XLENGTH(uids);
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, n));
+  SEXP nms = PROTECT(Rf_allocVector(STRSXP, n));
+  for (R_xlen_t i = 0; i < n; i++) {
+    char key[32];
+    SEXP cl = PROTECT(Rf_allocVector(INTSXP, 2));
+    INTEGER(cl)[0] = INTEGER(counts)[i];
+    INTEGER(cl)[1] = INTEGER(location)[i];
+    SET_VECTOR_ELT(out, i, cl);
+    snprintf(key, sizeof key, "%d", INTEGER(uids)[i]);
+    SET_STRING_ELT(nms, i, Rf_mkChar(key));
+    UNPROTECT(1);
+  }
+  Rf_setAttrib(out, R_NamesSymbol, nms);
+  UNPROTECT(2);
+  return out;
+}
+
+/* getRels3 (wrapper.cpp:18-48): data.frame(srcuid, trguid, sign, trguid2, sign2), one row per 2-edge walk */
+SEXP _geneticsCRE_getRels3(SEXP srcuid, SEXP trguid, SEXP sign, SEXP count_locs) {
+  load_abi();
+  const R_xlen_t n = XLENGTH(trguid);
+  int32_t *keys, *counts, *locs;
+  R_xlen_t nk;
+  flatten_count_locs(count_locs, &keys, &counts, &locs, &nk);
+  int32_t* oc = (int32_t*)R_alloc(n ? n : 1, sizeof(int32_t));
+  int64_t* ol = (int64_t*)R_alloc(n ? n : 1, sizeof(int64_t));
+  if (G.resolve(INTEGER(trguid), n, keys, counts, locs, nk, oc, ol) != GCRE_OK) Rf_error("geneticsCRE: resolve failed");
+  R_xlen_t total = 0;
+  for (R_xlen_t i = 0; i < n; i++) total += oc[i] > 0 ? oc[i] : 0;
+  SEXP cols[5];
+  for (int c = 0; c < 5; c++) cols[c] = PROTECT(Rf_allocVector(INTSXP, total));
+  R_xlen_t o = 0;
+  for (R_xlen_t i = 0; i < n; i++)
+    for (int64_t j = ol[i]; j < ol[i] + (oc[i] > 0 ? oc[i] : 0); j++, o++) {
+      INTEGER(cols[0])[o] = INTEGER(srcuid)[i];
+      INTEGER(cols[1])[o] = INTEGER(trguid)[i];
+      INTEGER(cols[2])[o] = INTEGER(sign)[i];
+      INTEGER(cols[3])[o] = INTEGER(trguid)[j];
+      INTEGER(cols[4])[o] = INTEGER(sign)[j];
+    }
+  static const char* names[5] = {"srcuid", "trguid", "sign", "trguid2", "sign2"};
+  SEXP df = PROTECT(Rf_allocVector(VECSXP, 5));
+  SEXP nms = PROTECT(Rf_allocVector(STRSXP, 5));
+  for (int c = 0; c < 5; c++) {
+    SET_VECTOR_ELT(df, c, cols[c]);
+    SET_STRING_ELT(nms, c, Rf_mkChar(names[c]));
+  }
+  Rf_setAttrib(df, R_NamesSymbol, nms);
+  SEXP rn = PROTECT(Rf_allocVector(INTSXP, 2));         /* compact row names c(NA, -n) */
+  INTEGER(rn)[0] = NA_INTEGER;
+  INTEGER(rn)[1] = -(int)total;
+  Rf_setAttrib(df, R_RowNamesSymbol, rn);
+  Rf_setAttrib(df, R_ClassSymbol, Rf_mkString("data.frame"));
+  UNPROTECT(8);
+  return df;
+}
+
+static const R_CallMethodDef CallEntries[] = {
+    {"_geneticsCRE_getRels3", (DL_FUNC)&_geneticsCRE_getRels3, 4},
+    {"_geneticsCRE_getMatchingList", (DL_FUNC)&_geneticsCRE_getMatchingList, 3},
+    {"_geneticsCRE_ProcessPaths", (DL_FUNC)&_geneticsCRE_ProcessPaths, 39},
+    {NULL, NULL, 0}};
+
+void R_init_geneticsCRE(DllInfo* dll) {
+  R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+  R_useDynamicSymbols(dll, FALSE);
+}
