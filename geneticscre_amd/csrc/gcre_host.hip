@@ -761,7 +761,10 @@ gcre_pathset* gcre_pathset_from_words(gcre_ctx* c, const uint64_t* rows, int64_t
     for (int h = 0; h < g.method; h++)
       std::memcpy(&dev[(size_t)r * g.S + (size_t)h * g.Wp], &rows[(size_t)r * g.W * g.method + (size_t)h * g.W],
                   (size_t)g.W * 8);
-  if (hipMemcpy(ps->d_rows, dev.data(), dev.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+  // same (non-blocking) stream as the zero-fill in new_pathset: a null-stream copy would race with it
+  hipError_t e = hipMemcpyAsync(ps->d_rows, dev.data(), dev.size() * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
     fail(c, GCRE_ERR_DEVICE, "pathset_from_words: copy failed");
     gcre_pathset_free(ps);
     return nullptr;

@@ -53,8 +53,10 @@ __device__ __forceinline__ void read_mask_row(const u32* lds_row, int lane, u32 
     m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
   } else {
     static_assert(R == 8, "R in {1,2,4,8}");
-    u32x4 v = *(const u32x4*)(lds_row + lane * 8);
-    u32x4 w = *(const u32x4*)(lds_row + lane * 8 + 4);
+    // lane owns permutations {4*lane .. 4*lane+3} and {256 + 4*lane ..}: both ds_read_b128 have a 16-byte lane
+    // stride (a 32-byte stride is a 2-way bank conflict for b128 reads)
+    u32x4 v = *(const u32x4*)(lds_row + lane * 4);
+    u32x4 w = *(const u32x4*)(lds_row + 256 + lane * 4);
     m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
     m[4] = w.x; m[5] = w.y; m[6] = w.z; m[7] = w.w;
   }
@@ -240,7 +242,11 @@ __global__ __launch_bounds__(kNullBlock, OCC) void k_null(const NullArgs a) {
 
   // ---- block reduction, then one atomic per permutation ----
 #pragma unroll
-  for (int j = 0; j < R; j++) red[wave][lane * R + j] = nmax[j];
+  for (int j = 0; j < R; j++) {
+    // register j of a lane <-> column of the permutation tile (see read_mask_row)
+    const int col = (R == 8) ? ((j >> 2) * 256 + lane * 4 + (j & 3)) : (lane * R + j);
+    red[wave][col] = nmax[j];
+  }
   __syncthreads();
   for (int i = tid; i < PT; i += kNullBlock) {
     u32 v = red[0][i];
