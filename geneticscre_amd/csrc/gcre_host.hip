@@ -80,6 +80,10 @@ struct gcre_ctx {
   double* d_dvt = nullptr;           // observed-score table
   double* d_dmax = nullptr;          // method 2 null table (vtmax)
   uint32_t* d_null = nullptr;        // [Kpad]
+  uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
+  uint32_t* d_max_tot = nullptr;     // 1 word: largest carrier total of the current chunk
+  int null_kernel = 0;               // 0 auto, 1 dense, 2 sparse (GCRE_NULL_KERNEL)
+  int sparse_waves_per_cu = 16;
 
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
@@ -109,6 +113,9 @@ struct gcre_uids {
   int64_t* d_path_idx;
   int64_t* d_location;
   int32_t* d_signs;
+  std::vector<int64_t> h_path_idx;   // host copy, for building the sparse kernel's segment tables
+  struct SegCache { int64_t first, count; int64_t nsegs; SparseSeg* d_segs; };
+  mutable std::vector<SegCache> seg_cache;
 };
 
 namespace {
@@ -180,6 +187,59 @@ gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
     }
   }
   return ps;
+}
+
+// The sparse kernel handles method 1 with patient indices that fit 16 bits; GCRE_NULL_KERNEL=dense turns it off.
+bool sparse_enabled(const gcre_ctx* c) {
+  return c->null_kernel != 1 && c->g.method == 1 && c->g.K > 0 && 64 * c->g.Wp < 65535;
+}
+
+int build_transposed_masks(gcre_ctx* c) {
+  if (!sparse_enabled(c)) return GCRE_OK;
+  const Geometry& g = c->g;
+  const int nkt = (g.K + kSparseTile - 1) / kSparseTile;
+  const uint32_t mt_rows = (uint32_t)(64 * g.Wp + 1);
+  const size_t bytes = (size_t)nkt * mt_rows * 64 * 4;
+  if (!c->d_mt) HIP_TRY(c, hipMalloc((void**)&c->d_mt, bytes));
+  HIP_TRY(c, hipMemsetAsync(c->d_mt, 0, bytes, c->stream));
+  HIP_TRY(c, launch_build_mt(c->d_masks, 2 * g.Wp, g.Kpad, nkt, mt_rows, c->d_mt, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return GCRE_OK;
+}
+
+// Segment table of the joined paths [first, first+count): runs of paths that share their paths0 row, at most
+// kSparseSegMax long.  Cached per uids object (the join index is resident input; repeated joins reuse it).
+int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t count, const SparseSeg** d_out,
+                    int64_t* nsegs) {
+  for (const auto& sc : u.seg_cache)
+    if (sc.first == first && sc.count == count) {
+      *d_out = sc.d_segs;
+      *nsegs = sc.nsegs;
+      return GCRE_OK;
+    }
+  std::vector<SparseSeg> segs;
+  const auto& pi = u.h_path_idx;
+  const int64_t end = first + count;
+  // first uid whose range reaches past `first`
+  int64_t i = std::upper_bound(pi.begin(), pi.end(), first) - pi.begin() - 1;
+  for (; i < u.n_uids && pi[(size_t)i] < end; i++) {
+    int64_t lo = std::max(pi[(size_t)i], first), hi = std::min(pi[(size_t)i + 1], end);
+    for (; lo < hi; lo += kSparseSegMax)
+      segs.push_back(SparseSeg{(uint32_t)i, (uint32_t)(lo - first), (uint32_t)std::min<int64_t>(kSparseSegMax, hi - lo)});
+  }
+  SparseSeg* d = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d, std::max<size_t>(segs.size(), 1) * sizeof(SparseSeg)));
+  if (!segs.empty())
+    HIP_TRY(c, hipMemcpyAsync(d, segs.data(), segs.size() * sizeof(SparseSeg), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // segs is a local
+  if (u.seg_cache.size() >= 64) {                // bound the cache: drop the oldest table
+    (void)hipFree(u.seg_cache.front().d_segs);
+    u.seg_cache.erase(u.seg_cache.begin());
+  }
+  u.seg_cache.push_back({first, count, (int64_t)segs.size(), d});
+  *d_out = d;
+  *nsegs = (int64_t)segs.size();
+  return GCRE_OK;
 }
 
 // ---- top-k selection of one scored chunk: indices of the best min(k, valid) keys, ties cut in index order ----
@@ -263,14 +323,17 @@ void free_uids(gcre_uids* u) {
   if (u->ctx && u->ctx->stream) (void)hipStreamSynchronize(u->ctx->stream);
   for (void* p : {(void*)u->d_path_idx, (void*)u->d_location, (void*)u->d_signs})
     if (p) (void)hipFree(p);
+  for (auto& sc : u->seg_cache)
+    if (sc.d_segs) (void)hipFree(sc.d_segs);
   delete u;
 }
 
 // validation that does not need the path sets (join_base.cpp:198-200 checks the rest in run_join)
 gcre_uids* make_uids(gcre_ctx* c, int path_length, const int32_t* uid_count, const int64_t* uid_location,
                      int64_t n_uids, const int32_t* signs, int64_t n_signs) {
-  auto* u = new gcre_uids{c, path_length, n_uids, n_signs, 0, -1, -1, nullptr, nullptr, nullptr};
-  std::vector<int64_t> path_idx((size_t)n_uids + 1, 0);
+  auto* u = new gcre_uids{c, path_length, n_uids, n_signs, 0, -1, -1, nullptr, nullptr, nullptr, {}, {}};
+  std::vector<int64_t>& path_idx = u->h_path_idx;
+  path_idx.assign((size_t)n_uids + 1, 0);
   for (int64_t i = 0; i < n_uids; i++) {
     const int cnt = uid_count[i];
     if (cnt > 0) {
@@ -393,12 +456,48 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         sa.count = n;
         sa.S = g.S;
         sa.Wp = g.Wp;
+        const bool use_sparse = sg.score && sparse_enabled(c) && c->d_mt != nullptr;
+        if (use_sparse) {
+          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 4, st));
+          sa.max_tot = c->d_max_tot;
+        }
         HIP_TRY(c, launch_stats(sa, g.method, st));
         HIP_TRY(c, hipEventRecord(e1, st));
         c->ev_stats.emplace_back(e0, e1);
         if (!sg.score) continue;
 
-        if (g.K > 0) {
+        if (g.K > 0 && use_sparse) {
+          uint32_t max_tot = 0;
+          HIP_TRY(c, hipMemcpyAsync(&max_tot, c->d_max_tot, 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipStreamSynchronize(st));
+          int planes = 5;
+          while (planes < 16 && (max_tot >> planes) != 0) planes++;
+          SparseArgs sp{};
+          HIP_TRY(c, (hipError_t)(sparse_segments(c, u, cb, n, &sp.segs, &sp.nsegs) == GCRE_OK ? hipSuccess : hipErrorUnknown));
+          sp.p0 = (const uint32_t*)jp.p0->d_rows;
+          sp.p1 = (const uint32_t*)jp.p1->d_rows;
+          sp.mt = c->d_mt;
+          sp.row1 = c->d_row1.p;
+          sp.tot = c->d_tot.p;
+          sp.t32 = c->d_t32;
+          sp.null_bits = c->d_null;
+          sp.S32 = 2 * g.S;
+          sp.W32p = 2 * g.Wp;
+          sp.nkt = (g.K + kSparseTile - 1) / kSparseTile;
+          sp.mt_rows = (uint32_t)(64 * g.Wp + 1);
+          int dev_cus = 256;
+          (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+          int64_t streams = std::max<int64_t>(1, (int64_t)dev_cus * c->sparse_waves_per_cu / sp.nkt);
+          sp.nstreams = (int)std::min<int64_t>(streams, std::max<int64_t>(sp.nsegs, 1));
+          hipEvent_t n0 = get_event(c), n1 = get_event(c);
+          HIP_TRY(c, hipEventRecord(n0, st));
+          HIP_TRY(c, launch_null_sparse(sp, planes, st));
+          HIP_TRY(c, hipEventRecord(n1, st));
+          c->ev_null.emplace_back(n0, n1);
+          c->prof.null_kernel_launches++;
+          c->prof.null_alg_bytes += (double)n * (2.0 * g.S * 8 + 8.0 + 4.0 * g.method) +
+                                    (double)(2 * g.Wp) * g.K * 4.0 + (double)g.K * 4.0;
+        } else if (g.K > 0) {
           NullArgs na{};
           na.p0 = (const uint32_t*)jp.p0->d_rows;
           na.p1 = (const uint32_t*)jp.p1->d_rows;
@@ -565,9 +664,13 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   if (const char* e = std::getenv("GCRE_QUIET")) c->quiet = std::atoi(e) != 0;
   if (const char* e = std::getenv("GCRE_CHUNK_PATHS")) c->chunk_paths = std::max<long long>(64, std::atoll(e));
   if (const char* e = std::getenv("GCRE_NULL_BLOCKS_PER_CU")) c->null_blocks_per_cu = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("GCRE_NULL_KERNEL"))
+    c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : 0;
+  if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));
 
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_case_mask, (size_t)g.Wp * 8) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_max_tot, 4) == hipSuccess;
   if (ok && g.Kpad > 0) {
     ok = hipMalloc((void**)&c->d_masks, (size_t)2 * g.Wp * g.Kpad * 4) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_null, (size_t)g.Kpad * 4) == hipSuccess;
@@ -592,7 +695,7 @@ void gcre_destroy(gcre_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void* p : {(void*)c->d_case_mask, (void*)c->d_masks, (void*)c->d_t32, (void*)c->d_dvt, (void*)c->d_dmax,
-                  (void*)c->d_null})
+                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot})
     if (p) (void)hipFree(p);
   for (auto* b : {&c->d_row0, &c->d_row1, &c->d_tot, &c->d_cases, &c->d_ctrls, &c->d_sel, &c->d_small, &c->d_chunk,
                   &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})
@@ -691,6 +794,7 @@ int gcre_set_perm_cases(gcre_ctx* c, const int32_t* perms, int nrow, int ncol, i
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d_in);
   if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("set_perm_cases: ") + hipGetErrorString(e));
+  if (int rc = build_transposed_masks(c)) return rc;
   c->have_perms = true;
   return GCRE_OK;
 }
@@ -709,6 +813,7 @@ int gcre_set_perm_masks(gcre_ctx* c, const uint64_t* masks, int nrow) {
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d_in);
   if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("set_perm_masks: ") + hipGetErrorString(e));
+  if (int rc = build_transposed_masks(c)) return rc;
   c->have_perms = true;
   return GCRE_OK;
 }

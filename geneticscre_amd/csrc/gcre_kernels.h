@@ -26,7 +26,7 @@ struct Geometry {
   int TD;       // number of table diagonals = 64*Wp + 1
 };
 
-constexpr int kPermTileMax = 512;      // Kpad granularity
+constexpr int kPermTileMax = 2048;     // Kpad granularity (the sparse kernel's permutation tile)
 constexpr int kNullBlock = 256;        // threads per block of the null kernel
 
 struct NullArgs {
@@ -59,6 +59,35 @@ NullConfig null_config(int method, int K);
 // grid is derived from the args (nkt * pgroups blocks)
 hipError_t launch_null(const NullArgs& a, int method, const NullConfig& cfg, hipStream_t stream);
 
+// ---- sparse / bit-sliced null kernel (gcre_sparse.hip) ----
+struct SparseSeg {
+  uint32_t row0;    // row of paths0 shared by the segment's joined paths
+  uint32_t first;   // first joined path of the segment, relative to the launch
+  uint32_t n;       // joined paths in the segment
+};
+
+struct SparseArgs {
+  const uint32_t* p0;
+  const uint32_t* p1;
+  const uint32_t* mt;        // transposed masks [nkt][mt_rows][64]; row mt_rows-1 is all zero
+  const uint32_t* row1;      // per joined path of the launch
+  const uint32_t* tot;
+  const SparseSeg* segs;
+  const float* t32;
+  uint32_t* null_bits;
+  int64_t nsegs;
+  int S32;
+  int W32p;
+  int nkt;                   // 2048-permutation tiles
+  int nstreams;              // waves per tile
+  uint32_t mt_rows;
+};
+constexpr int kSparseTile = 2048;
+constexpr int kSparseSegMax = 64;
+hipError_t launch_null_sparse(const SparseArgs& a, int planes, hipStream_t stream);
+hipError_t launch_build_mt(const uint32_t* masks, int W32p, int Kpad, int nkt, uint32_t mt_rows, uint32_t* mt,
+                           hipStream_t stream);
+
 hipError_t launch_pack_dense(const int32_t* data, int64_t nrow, int ncol, int col_major, uint64_t* rows, int S,
                              hipStream_t stream);
 hipError_t launch_select(const uint64_t* from, const int32_t* idx, int64_t n, int S, uint64_t* out, hipStream_t stream);
@@ -84,6 +113,7 @@ struct StatsArgs {
   uint32_t* cases;
   uint32_t* ctrls;
   uint64_t* res;               // kept rows, indexed by absolute ordinal (first + i), or nullptr
+  uint32_t* max_tot;           // optional: running maximum of the carrier totals (sizes the sparse kernel's counters)
   int64_t first;
   int64_t count;
   int S;

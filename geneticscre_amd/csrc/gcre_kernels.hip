@@ -455,6 +455,7 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
   const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
   const int Wp = a.Wp;
+  u32 wave_max_tot = 0;
   for (i64 i = wave; i < a.count; i += nwaves) {
     const u32 r0 = a.row0[i];
     const u32 r1raw = a.row1[i];
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
         a.tot[i] = total;
         a.cases[i] = cs;
         a.ctrls[i] = ct;
+        wave_max_tot = max(wave_max_tot, total);
       }
     } else {
       const bool swap = (r1raw >> 31) != 0;
@@ -509,9 +511,11 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
         a.tot[2 * i + 1] = tn;
         a.cases[i] = case_pos + case_neg;       // methods.h:256-257
         a.ctrls[i] = ctrl_pos + ctrl_neg;
+        wave_max_tot = max(wave_max_tot, max(tp, tn));
       }
     }
   }
+  if (a.max_tot && lane == 0 && wave_max_tot) atomicMax(a.max_tot, wave_max_tot);
 }
 
 hipError_t launch_stats(const StatsArgs& a, int method, hipStream_t stream) {
