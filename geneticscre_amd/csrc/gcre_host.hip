@@ -487,8 +487,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sp.mt_rows = (uint32_t)(64 * g.Wp + 1);
           int dev_cus = 256;
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-          int64_t streams = std::max<int64_t>(1, (int64_t)dev_cus * c->sparse_waves_per_cu / sp.nkt);
-          sp.nstreams = (int)std::min<int64_t>(streams, std::max<int64_t>(sp.nsegs, 1));
+          if (const char* e = std::getenv("GCRE_SPARSE_ABLATE")) sp.ablate = std::atoi(e);
+          sp.waves_per_xcd = std::max(4, (dev_cus * c->sparse_waves_per_cu / 8 / 4) * 4);
           hipEvent_t n0 = get_event(c), n1 = get_event(c);
           HIP_TRY(c, hipEventRecord(n0, st));
           HIP_TRY(c, launch_null_sparse(sp, planes, st));

@@ -79,8 +79,9 @@ struct SparseArgs {
   int S32;
   int W32p;
   int nkt;                   // 2048-permutation tiles
-  int nstreams;              // waves per tile
+  int waves_per_xcd;         // persistent waves per XCD (grid = 8 * waves_per_xcd / 4 blocks)
   uint32_t mt_rows;
+  int ablate;                // diagnostics only (GCRE_SPARSE_ABLATE): 1 no mask loads, 2 no table gathers, 4 no accumulate
 };
 constexpr int kSparseTile = 2048;
 constexpr int kSparseSegMax = 64;

@@ -31,7 +31,8 @@ typedef uint16_t u16;
 typedef u32 __attribute__((ext_vector_type(4))) u32x4;
 
 constexpr int kSparseWaves = 4;           // waves per block, each fully independent
-constexpr int kListCap = 2048 + 16;       // bit indices of one 64-dword chunk + padding
+constexpr int kListFlush = 1024;          // accumulate once the list holds more than this many indices
+constexpr int kListCap = kListFlush + 2048 + 16;   // + one worst-case chunk + padding
 
 __device__ __forceinline__ u32 sp_diag_offset(u32 t) { return (u32)(((u64)t * (u64)(t + 1)) >> 1); }
 
@@ -42,45 +43,67 @@ __device__ __forceinline__ void csa(u32& hi, u32& lo, u32 a, u32 b, u32 c) {
   lo = u ^ c;
 }
 
-// Indices (patient numbers) of the set bits of one 64-dword chunk of a row, in LDS; lane l owns dword l.
-// Returns the number of indices (wave-uniform).  The list is padded with `zrow` up to a multiple of 16.
-__device__ __forceinline__ u32 build_list(u16* list, u32 w, u32 chunk, int lane, u32 zrow) {
+// inclusive prefix sum over the 64 lanes on the DPP crossbar (no LDS traffic): row_shr 1/2/3, then 4 and 8 inside
+// each row of 16, then row_bcast:15 / row_bcast:31 carry the row totals forward
+__device__ __forceinline__ u32 wave_scan_add(u32 v) {
+  u32 s = v;
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);   // row_shr:3
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xe, true);   // row_shr:4, banks 1-3
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xc, true);   // row_shr:8, banks 2-3
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+  return s;
+}
+
+// Append the indices (patient numbers) of the set bits of one 64-dword chunk of a row to the LDS list; lane l
+// owns dword l of the chunk.  `nb` (wave-uniform) is the list length before and after.
+__device__ __forceinline__ u32 append_list(u16* list, u32 nb, u32 w, u32 chunk, int lane) {
   const u32 cnt = __builtin_popcount(w);
-  u32 incl = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const u32 t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  const u32 nb = __builtin_amdgcn_readlane(incl, 63);
-  u32 pos = incl - cnt;
+  const u32 incl = wave_scan_add(cnt);
+  u32 pos = nb + incl - cnt;
   const u32 base = chunk * 2048u + (u32)lane * 32u;
   while (w) {
     const u32 b = __builtin_ctz(w);
     list[pos++] = (u16)(base + b);
     w &= w - 1;
   }
+  return nb + __builtin_amdgcn_readlane(incl, 63);
+}
+
+// pad the list with the all-zero mask row up to a multiple of 16 and make it visible to the whole wave
+__device__ __forceinline__ void seal_list(u16* list, u32 nb, int lane, u32 zrow) {
   if (lane < 16) list[nb + lane] = (u16)zrow;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  return nb;
 }
 
 // Add the mask rows of `nb` listed patients into the L counter planes P (plane l = bit l of the counts).
 template <int L>
-__device__ __forceinline__ void accumulate(u32 (&P)[L], const u16* list, u32 nb, const u32* mt_lane) {
+__device__ __forceinline__ void accumulate(u32 (&P)[L], const u16* list, u32 nb, const u32* mt_lane, int ablate = 0) {
+  if (ablate & 4) return;
   static_assert(L >= 5, "planes 0..3 are the CSA tree's ones/twos/fours/eights");
   for (u32 base = 0; base < nb; base += 16) {
     const u32x4 ia = *(const u32x4*)(list + base);        // 8 indices, broadcast read
     const u32x4 ib = *(const u32x4*)(list + base + 8);
     u32 x[16];
+    if (ablate & 1) {   // diagnostics: no mask-row loads
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      x[2 * j] = mt_lane[(size_t)(ia[j] & 0xffffu) << 6];
-      x[2 * j + 1] = mt_lane[(size_t)(ia[j] >> 16) << 6];
-      x[8 + 2 * j] = mt_lane[(size_t)(ib[j] & 0xffffu) << 6];
-      x[8 + 2 * j + 1] = mt_lane[(size_t)(ib[j] >> 16) << 6];
+      for (int j = 0; j < 4; j++) {
+        x[2 * j] = ia[j]; x[2 * j + 1] = ia[j] * 3u; x[8 + 2 * j] = ib[j]; x[8 + 2 * j + 1] = ib[j] * 5u;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        // row i of the tile starts i*256 bytes in (< 16 MB: a 32-bit offset); one v_perm_b32 turns a packed
+        // index into that offset: bytes {0, idx.lo, idx.hi, 0}
+        x[2 * j] = *(const u32*)((const char*)mt_lane + __builtin_amdgcn_perm(0u, ia[j], 0x0c01000cu));
+        x[2 * j + 1] = *(const u32*)((const char*)mt_lane + __builtin_amdgcn_perm(0u, ia[j], 0x0c03020cu));
+        x[8 + 2 * j] = *(const u32*)((const char*)mt_lane + __builtin_amdgcn_perm(0u, ib[j], 0x0c01000cu));
+        x[8 + 2 * j + 1] = *(const u32*)((const char*)mt_lane + __builtin_amdgcn_perm(0u, ib[j], 0x0c03020cu));
+      }
     }
     u32 t0, t1, t2, t3, f0, f1, e0, e1, s;
     csa(t0, P[0], P[0], x[0], x[1]);
@@ -131,21 +154,45 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
   __shared__ __attribute__((aligned(16))) u16 lists[kSparseWaves][kListCap];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const i64 gw = (i64)blockIdx.x * kSparseWaves + wave;
-  const int kt = (int)(gw % a.nkt);
-  const i64 stream = gw / a.nkt;
-  if (stream >= a.nstreams) return;          // whole wave leaves; there are no block barriers in this kernel
+  // Work items are (permutation tile kt, slice sl of the segment list), ordered kt-major.  Workgroups that share
+  // an XCD (blockIdx % 8, MI355X_MICROARCH "Workgroup dispatch") own a contiguous range of items and walk it in
+  // step, so at any time an XCD's L2 holds the transposed masks of one or two tiles only.  Pure speed: any
+  // other block placement gives the same results.
+  const int xcd = blockIdx.x & 7;
+  const i64 wi = (i64)(blockIdx.x >> 3) * kSparseWaves + wave;       // wave index inside the XCD
+  const i64 wx = a.waves_per_xcd;
+  const i64 slices = 8 * wx;                                         // slices per permutation tile
   u16* list = lists[wave];
   const u32 zrow = a.mt_rows - 1;
-  const u32* mt_lane = a.mt + (size_t)kt * a.mt_rows * 64 + lane;
   const int nch = (a.W32p + 63) >> 6;
   const SparseSeg* segs = (const SparseSeg*)a.segs;
 
   u32 nmax[32];
 #pragma unroll
   for (int q = 0; q < 32; q++) nmax[q] = 0u;
+  int cur_kt = -1;
+  const u32* mt_lane = a.mt + lane;
 
-  for (i64 sidx = stream; sidx < a.nsegs; sidx += a.nstreams) {
+  auto flush = [&]() {
+    if (cur_kt < 0) return;
+    u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      if (nmax[q] != 0u) atomicMax(out + q, nmax[q]);
+      nmax[q] = 0u;
+    }
+  };
+
+  for (int step = 0; step < a.nkt; step++) {
+   const i64 item = (i64)xcd * a.nkt * wx + wi + (i64)step * wx;
+   const int kt = (int)(item / slices);
+   const i64 sl = item % slices;
+   if (kt != cur_kt) {
+     flush();
+     cur_kt = kt;
+     mt_lane = a.mt + (size_t)kt * a.mt_rows * 64 + lane;
+   }
+   for (i64 sidx = sl; sidx < a.nsegs; sidx += slices) {
     const u32 row0 = __builtin_amdgcn_readfirstlane(segs[sidx].row0);
     const u32 first = __builtin_amdgcn_readfirstlane(segs[sidx].first);
     const u32 npaths = __builtin_amdgcn_readfirstlane(segs[sidx].n);
@@ -155,11 +202,18 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
     u32 B[L];
 #pragma unroll
     for (int l = 0; l < L; l++) B[l] = 0u;
-    for (int c = 0; c < nch; c++) {
-      const int k = c * 64 + lane;
-      const u32 w = (k < a.W32p) ? r0[k] : 0u;
-      const u32 nb = build_list(list, w, (u32)c, lane, zrow);
-      accumulate<L>(B, list, nb, mt_lane);
+    {
+      u32 nb = 0;
+      for (int c = 0; c < nch; c++) {
+        const int k = c * 64 + lane;
+        const u32 w = (k < a.W32p) ? r0[k] : 0u;
+        nb = append_list(list, nb, w, (u32)c, lane);
+        if (nb > kListFlush || c + 1 == nch) {
+          seal_list(list, nb, lane, zrow);
+          accumulate<L>(B, list, nb, mt_lane, a.ablate);
+          nb = 0;
+        }
+      }
     }
 
     for (u32 t = 0; t < npaths; t++) {
@@ -170,11 +224,16 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
 #pragma unroll
       for (int l = 0; l < L; l++) C[l] = B[l];
       // only the bits paths1 adds on top of paths0
+      u32 nb = 0;
       for (int c = 0; c < nch; c++) {
         const int k = c * 64 + lane;
         const u32 w = (k < a.W32p) ? (r1[k] & ~r0[k]) : 0u;
-        const u32 nb = build_list(list, w, (u32)c, lane, zrow);
-        accumulate<L>(C, list, nb, mt_lane);
+        nb = append_list(list, nb, w, (u32)c, lane);
+        if (nb > kListFlush || c + 1 == nch) {
+          seal_list(list, nb, lane, zrow);
+          accumulate<L>(C, list, nb, mt_lane, a.ablate);
+          nb = 0;
+        }
       }
 
       // counters -> 32 integers per lane -> table diagonal -> running maxima (methods.h:96-103)
@@ -186,23 +245,23 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
       const char* diag = (const char*)((const u32*)a.t32 + sp_diag_offset(total));
 #pragma unroll
       for (int j = 0; j < 16; j++) {
-        const u32 lo = *(const u32*)(diag + ((R[j] & 0xffffu) << 2));
-        const u32 hi = *(const u32*)(diag + ((R[j] >> 16) << 2));
+        u32 lo, hi;
+        if (a.ablate & 2) { lo = R[j] & 0xffffu; hi = R[j] >> 16; }
+        else {
+          lo = *(const u32*)(diag + ((R[j] & 0xffffu) << 2));
+          hi = *(const u32*)(diag + ((R[j] >> 16) << 2));
+        }
         nmax[j] = (lo > nmax[j]) ? lo : nmax[j];
         nmax[j + 16] = (hi > nmax[j + 16]) ? hi : nmax[j + 16];
       }
     }
+   }
   }
-
-  u32* out = a.null_bits + (size_t)kt * 2048 + lane * 32;
-#pragma unroll
-  for (int q = 0; q < 32; q++)
-    if (nmax[q] != 0u) atomicMax(out + q, nmax[q]);
+  flush();
 }
 
 hipError_t launch_null_sparse(const SparseArgs& a, int planes, hipStream_t stream) {
-  const i64 waves = (i64)a.nkt * a.nstreams;
-  const dim3 grid((unsigned)((waves + kSparseWaves - 1) / kSparseWaves));
+  const dim3 grid((unsigned)(8 * a.waves_per_xcd / kSparseWaves));
   const dim3 block(64 * kSparseWaves);
   if (planes <= 8) hipLaunchKernelGGL(k_null_sparse<8>, grid, block, 0, stream, a);
   else if (planes <= 10) hipLaunchKernelGGL(k_null_sparse<10>, grid, block, 0, stream, a);
