@@ -83,11 +83,12 @@ struct gcre_ctx {
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
   uint32_t* d_max_tot = nullptr;     // 1 word: largest carrier total of the current chunk
   int null_kernel = 0;               // 0 auto, 1 dense, 2 sparse (GCRE_NULL_KERNEL)
-  int sparse_waves_per_cu = 16;
+  int sparse_waves_per_cu = 32;
 
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
-  DevBuf<uint64_t> d_key, d_wkey;
+  DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan;
+  DevBuf<uint32_t> d_dcnt, d_dlist;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
 
   gcre_profile prof{};
@@ -99,6 +100,9 @@ struct gcre_pathset {
   gcre_ctx* ctx;
   int64_t nrows;
   uint64_t* d_rows;   // max(nrows,1) x S words
+  // CSR bit lists for the sparse kernel, built on first use and dropped whenever the rows are rewritten
+  mutable uint64_t* d_loff = nullptr;
+  mutable uint32_t* d_lidx = nullptr;
 };
 
 // UidRelSet (src/gcre.h:49-90) resident on the device: prefix sums of count, locations, signs
@@ -171,7 +175,7 @@ gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
     fail(c, GCRE_ERR_RANGE, "path set too large for 32-bit row addressing");
     return nullptr;
   }
-  auto* ps = new gcre_pathset{c, nrows, nullptr};
+  auto* ps = new gcre_pathset{c, nrows, nullptr, nullptr, nullptr};
   const size_t bytes = (size_t)std::max<int64_t>(nrows, 1) * c->g.S * sizeof(uint64_t);
   if (hipMalloc((void**)&ps->d_rows, bytes) != hipSuccess) {
     fail(c, GCRE_ERR_DEVICE, "hipMalloc failed for a path set of " + std::to_string(bytes) + " bytes");
@@ -204,6 +208,43 @@ int build_transposed_masks(gcre_ctx* c) {
   HIP_TRY(c, hipMemsetAsync(c->d_mt, 0, bytes, c->stream));
   HIP_TRY(c, launch_build_mt(c->d_masks, 2 * g.Wp, g.Kpad, nkt, mt_rows, c->d_mt, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return GCRE_OK;
+}
+
+void drop_lists(const gcre_pathset* ps) {
+  if (ps->d_loff) (void)hipFree(ps->d_loff);
+  if (ps->d_lidx) (void)hipFree(ps->d_lidx);
+  ps->d_loff = nullptr;
+  ps->d_lidx = nullptr;
+}
+
+// CSR bit lists of a path set (method 1: one list per row): offsets on the host by prefix sum, entries on the device
+int ensure_lists(gcre_ctx* c, const gcre_pathset* ps) {
+  if (ps->d_loff) return GCRE_OK;
+  const Geometry& g = c->g;
+  const int64_t n = ps->nrows;
+  std::vector<uint32_t> cnt((size_t)std::max<int64_t>(n, 1), 0);
+  uint32_t* d_cnt = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_cnt, cnt.size() * 4));
+  hipError_t e = launch_row_bits((const uint32_t*)ps->d_rows, n, 2 * g.S, 2 * g.Wp, d_cnt, c->stream);
+  if (e == hipSuccess && n > 0) e = hipMemcpyAsync(cnt.data(), d_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_cnt);
+  if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("row lists: ") + hipGetErrorString(e));
+  std::vector<uint64_t> off((size_t)n + 1, 0);
+  for (int64_t r = 0; r < n; r++) off[(size_t)r + 1] = off[(size_t)r] + cnt[(size_t)r];
+  const uint64_t total = off[(size_t)n];
+  HIP_TRY(c, hipMalloc((void**)&ps->d_loff, off.size() * 8));
+  HIP_TRY(c, hipMalloc((void**)&ps->d_lidx, (size_t)std::max<uint64_t>(total, 16) * 4));
+  e = hipMemcpyAsync(ps->d_loff, off.data(), off.size() * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess)
+    e = launch_row_fill((const uint32_t*)ps->d_rows, n, 2 * g.S, 2 * g.Wp, ps->d_loff, (uint32_t)(64 * g.Wp) << 8,
+                        ps->d_lidx, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // off is a local
+  if (e != hipSuccess) {
+    drop_lists(ps);
+    return fail(c, GCRE_ERR_DEVICE, std::string("row lists: ") + hipGetErrorString(e));
+  }
   return GCRE_OK;
 }
 
@@ -384,6 +425,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   const bool keep = jp.res != nullptr && jp.res->nrows != 0;   // keep_paths = paths_res.size != 0, join_base.cpp:217
   if (jp.res && jp.res->nrows != 0 && jp.res->nrows != P)
     return fail(c, GCRE_ERR_ASSERT, "assertion: paths_res.size != total paths");
+  if (keep) drop_lists(jp.res);   // its rows are about to be rewritten
   if (g.method == 2 && P > 0) {
     // need_flip reads signs[idx] and/or signs[loc] (gcre.h:71-81); the reference would read out of bounds
     int64_t need_signs = 0;
@@ -460,6 +502,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         if (use_sparse) {
           HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 4, st));
           sa.max_tot = c->d_max_tot;
+          HIP_TRY(c, c->d_dcnt.reserve((size_t)n));
+          sa.dcnt = c->d_dcnt.p;
         }
         HIP_TRY(c, launch_stats(sa, g.method, st));
         HIP_TRY(c, hipEventRecord(e1, st));
@@ -467,28 +511,42 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         if (!sg.score) continue;
 
         if (g.K > 0 && use_sparse) {
+          // inspector (once per chunk, shared by all permutation tiles): per joined path the bits paths1 adds
+          // on top of paths0 -> offsets by a device scan of the counts k_stats left, entries by k_delta_fill
+          if (int rc = ensure_lists(c, jp.p0)) return rc;
+          if (int rc = ensure_lists(c, jp.p1)) return rc;
+          const uint32_t zoff = (uint32_t)(64 * g.Wp) << 8;
+          HIP_TRY(c, c->d_doff.reserve((size_t)n + 1));
+          HIP_TRY(c, c->d_scan.reserve((size_t)(n + 1023) / 1024 + 2));
+          HIP_TRY(c, launch_scan_u32_u64(c->d_dcnt.p, n, c->d_doff.p, c->d_scan.p, st));
           uint32_t max_tot = 0;
+          uint64_t n_delta = 0;
           HIP_TRY(c, hipMemcpyAsync(&max_tot, c->d_max_tot, 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(&n_delta, c->d_doff.p + n, 8, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipStreamSynchronize(st));
+          HIP_TRY(c, c->d_dlist.reserve((size_t)std::max<uint64_t>(n_delta, 16)));
+          HIP_TRY(c, launch_delta_fill((const uint32_t*)jp.p0->d_rows, 2 * g.S, c->d_row0.p, c->d_row1.p, n,
+                                       jp.p1->d_loff, jp.p1->d_lidx, c->d_doff.p, zoff, c->d_dlist.p, st));
           int planes = 5;
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           SparseArgs sp{};
-          HIP_TRY(c, (hipError_t)(sparse_segments(c, u, cb, n, &sp.segs, &sp.nsegs) == GCRE_OK ? hipSuccess : hipErrorUnknown));
-          sp.p0 = (const uint32_t*)jp.p0->d_rows;
-          sp.p1 = (const uint32_t*)jp.p1->d_rows;
+          if (int rc = sparse_segments(c, u, cb, n, &sp.segs, &sp.nsegs)) return rc;
           sp.mt = c->d_mt;
-          sp.row1 = c->d_row1.p;
           sp.tot = c->d_tot.p;
+          sp.loff0 = jp.p0->d_loff;
+          sp.lidx0 = jp.p0->d_lidx;
+          sp.doff = c->d_doff.p;
+          sp.dlist = c->d_dlist.p;
           sp.t32 = c->d_t32;
           sp.null_bits = c->d_null;
-          sp.S32 = 2 * g.S;
-          sp.W32p = 2 * g.Wp;
           sp.nkt = (g.K + kSparseTile - 1) / kSparseTile;
           sp.mt_rows = (uint32_t)(64 * g.Wp + 1);
+          sp.zoff = zoff;
           int dev_cus = 256;
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
           if (const char* e = std::getenv("GCRE_SPARSE_ABLATE")) sp.ablate = std::atoi(e);
-          sp.waves_per_xcd = std::max(4, (dev_cus * c->sparse_waves_per_cu / 8 / 4) * 4);
+          const int wpc = std::min(c->sparse_waves_per_cu, sparse_max_waves_per_cu(planes));
+          sp.waves_per_xcd = std::max(4, (dev_cus * wpc / 8 / 4) * 4);
           hipEvent_t n0 = get_event(c), n1 = get_event(c);
           HIP_TRY(c, hipEventRecord(n0, st));
           HIP_TRY(c, launch_null_sparse(sp, planes, st));
@@ -702,6 +760,10 @@ void gcre_destroy(gcre_ctx* c) {
     b->release();
   c->d_key.release();
   c->d_wkey.release();
+  c->d_doff.release();
+  c->d_scan.release();
+  c->d_dcnt.release();
+  c->d_dlist.release();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -928,6 +990,8 @@ void gcre_pathset_free(gcre_pathset* ps) {
     if (ps->ctx->stream) (void)hipStreamSynchronize(ps->ctx->stream);
   }
   if (ps->d_rows) (void)hipFree(ps->d_rows);
+  if (ps->d_loff) (void)hipFree(ps->d_loff);
+  if (ps->d_lidx) (void)hipFree(ps->d_lidx);
   delete ps;
 }
 

@@ -67,25 +67,35 @@ struct SparseSeg {
 };
 
 struct SparseArgs {
-  const uint32_t* p0;
-  const uint32_t* p1;
   const uint32_t* mt;        // transposed masks [nkt][mt_rows][64]; row mt_rows-1 is all zero
-  const uint32_t* row1;      // per joined path of the launch
-  const uint32_t* tot;
+  const uint32_t* tot;       // carriers per joined path of the launch
   const SparseSeg* segs;
+  const uint64_t* loff0;     // CSR bit lists of paths0: offsets [rows+1] ...
+  const uint32_t* lidx0;     // ... and entries = patient << 8 (byte offset of the patient's mask row), 16-padded
+  const uint64_t* doff;      // per joined path of the launch: [count+1] offsets into dlist
+  const uint32_t* dlist;     // entries of the bits paths1 adds on top of paths0, same encoding, 16-padded
   const float* t32;
   uint32_t* null_bits;
   int64_t nsegs;
-  int S32;
-  int W32p;
   int nkt;                   // 2048-permutation tiles
   int waves_per_xcd;         // persistent waves per XCD (grid = 8 * waves_per_xcd / 4 blocks)
   uint32_t mt_rows;
-  int ablate;                // diagnostics only (GCRE_SPARSE_ABLATE): 1 no mask loads, 2 no table gathers, 4 no accumulate
+  uint32_t zoff;             // byte offset of the all-zero mask row = (mt_rows - 1) * 256
+  int ablate;                // diagnostics only (GCRE_SPARSE_ABLATE)
 };
 constexpr int kSparseTile = 2048;
 constexpr int kSparseSegMax = 64;
 hipError_t launch_null_sparse(const SparseArgs& a, int planes, hipStream_t stream);
+int sparse_max_waves_per_cu(int planes);   // resident waves per CU of the variant chosen for `planes` counter planes
+// exclusive prefix sum of n u32 counts into n+1 u64 offsets (scratch: >= (n+1023)/1024 + 1 u64)
+hipError_t launch_scan_u32_u64(const uint32_t* cnt, int64_t n, uint64_t* off, uint64_t* scratch, hipStream_t stream);
+// per joined path: entries of paths1's list whose bit is clear in the paths0 row, 16-padded, at dlist[doff[i]..)
+hipError_t launch_delta_fill(const uint32_t* p0, int S32, const uint32_t* row0, const uint32_t* row1, int64_t count,
+                             const uint64_t* loff1, const uint32_t* lidx1, const uint64_t* doff, uint32_t zoff,
+                             uint32_t* dlist, hipStream_t stream);
+hipError_t launch_row_bits(const uint32_t* rows, int64_t nrows, int S32, int W32p, uint32_t* cnt, hipStream_t stream);
+hipError_t launch_row_fill(const uint32_t* rows, int64_t nrows, int S32, int W32p, const uint64_t* off, uint32_t zoff,
+                           uint32_t* idx, hipStream_t stream);
 hipError_t launch_build_mt(const uint32_t* masks, int W32p, int Kpad, int nkt, uint32_t mt_rows, uint32_t* mt,
                            hipStream_t stream);
 
@@ -115,6 +125,7 @@ struct StatsArgs {
   uint32_t* ctrls;
   uint64_t* res;               // kept rows, indexed by absolute ordinal (first + i), or nullptr
   uint32_t* max_tot;           // optional: running maximum of the carrier totals (sizes the sparse kernel's counters)
+  uint32_t* dcnt;              // optional (method 1): popcount(path1 & ~path0) rounded up to 16, per joined path
   int64_t first;
   int64_t count;
   int S;

@@ -464,16 +464,21 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
     const u64* y = a.p1 + (size_t)r1 * a.S;
     u64* out = a.res ? a.res + (size_t)(a.first + i) * a.S : nullptr;
     if constexpr (M == 1) {
-      u32 cs = 0, ct = 0;
+      u32 cs = 0, ct = 0, dl = 0;
       for (int k = lane; k < Wp; k += 64) {
         const u64 j = x[k] | y[k];
         const u64 cm = a.case_mask[k];
         cs += __popcll(j & cm);      // methods.h:77-78
         ct += __popcll(j & ~cm);
+        dl += __popcll(y[k] & ~x[k]);   // bits paths1 adds on top of paths0 (sparse kernel's per-path list length)
         if (out) out[k] = j;
       }
       cs = wave_sum(cs);
       ct = wave_sum(ct);
+      if (a.dcnt) {
+        dl = wave_sum(dl);
+        if (lane == 0) a.dcnt[i] = (dl + 15u) & ~15u;
+      }
       if (lane == 0) {
         const u32 total = cs + ct;
         const double s = a.dvt[(size_t)diag_offset(total) + cs];   // vt[cases][ctrls], methods.h:90

@@ -13,13 +13,19 @@
 // ~2.6 VALU ops per set bit per 32 permutations, against 3 issue slots (v_and + half-rate v_bcnt) per 32
 // *patients* per single permutation in the dense form -- the work drops by the bit density of the path.
 //
+// Set bits come from per-row index lists kept next to every path set (CSR: offsets + pre-scaled row offsets
+// into the mask tile, padded to blocks of 16 with the all-zero row).  They are wave-uniform, so they travel on
+// the scalar side: s_load_dwordx16 fetches 16 offsets, each becomes the scalar offset of one
+// buffer_load_dword (lane*4 is the vector offset) -- no VALU, no LDS for addressing.
+//
 // Joins that share their paths0 row (all `count` joins of one uid, join_base.cpp:242) share its bits: the
 // wave accumulates the bits of paths0[idx] once into base counters and per joined path only adds the bits
-// that paths1[loc] contributes on top (path1 & ~path0).
+// that paths1[loc] contributes on top: the entries of paths1's list whose bit is clear in paths0's row,
+// compacted with a ballot and pulled lane by lane (v_readlane) onto the scalar side.
 //
 // Per joined path the counters are transposed in-register (16x16 bit-matrix transpose on both halves of
 // every dword) into 32 integers, looked up on the path's table diagonal and max-ed into 32 running maxima
-// per lane.  Waves are independent: no barriers, per-wave LDS scratch for the bit-index list.
+// per lane.  Waves are independent: no barriers, no LDS.
 #include "gcre_kernels.h"
 
 namespace gcre {
@@ -27,12 +33,11 @@ namespace gcre {
 typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int64_t i64;
-typedef uint16_t u16;
-typedef u32 __attribute__((ext_vector_type(4))) u32x4;
+typedef u32 __attribute__((ext_vector_type(16))) u32x16;
+
+#define GCRE_CONSTANT __attribute__((address_space(4)))
 
 constexpr int kSparseWaves = 4;           // waves per block, each fully independent
-constexpr int kListFlush = 1024;          // accumulate once the list holds more than this many indices
-constexpr int kListCap = kListFlush + 2048 + 16;   // + one worst-case chunk + padding
 
 __device__ __forceinline__ u32 sp_diag_offset(u32 t) { return (u32)(((u64)t * (u64)(t + 1)) >> 1); }
 
@@ -57,77 +62,32 @@ __device__ __forceinline__ u32 wave_scan_add(u32 v) {
   return s;
 }
 
-// Append the indices (patient numbers) of the set bits of one 64-dword chunk of a row to the LDS list; lane l
-// owns dword l of the chunk.  `nb` (wave-uniform) is the list length before and after.
-__device__ __forceinline__ u32 append_list(u16* list, u32 nb, u32 w, u32 chunk, int lane) {
-  const u32 cnt = __builtin_popcount(w);
-  const u32 incl = wave_scan_add(cnt);
-  u32 pos = nb + incl - cnt;
-  const u32 base = chunk * 2048u + (u32)lane * 32u;
-  while (w) {
-    const u32 b = __builtin_ctz(w);
-    list[pos++] = (u16)(base + b);
-    w &= w - 1;
-  }
-  return nb + __builtin_amdgcn_readlane(incl, 63);
-}
-
-// pad the list with the all-zero mask row up to a multiple of 16 and make it visible to the whole wave
-__device__ __forceinline__ void seal_list(u16* list, u32 nb, int lane, u32 zrow) {
-  if (lane < 16) list[nb + lane] = (u16)zrow;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Add the mask rows of `nb` listed patients into the L counter planes P (plane l = bit l of the counts).
+// Add 16 mask rows (one dword per lane each) into the L counter planes P (plane l = bit l of the counts).
 template <int L>
-__device__ __forceinline__ void accumulate(u32 (&P)[L], const u16* list, u32 nb, const u32* mt_lane, int ablate = 0) {
-  if (ablate & 4) return;
+__device__ __forceinline__ void add16(u32 (&P)[L], const u32 (&x)[16]) {
   static_assert(L >= 5, "planes 0..3 are the CSA tree's ones/twos/fours/eights");
-  for (u32 base = 0; base < nb; base += 16) {
-    const u32x4 ia = *(const u32x4*)(list + base);        // 8 indices, broadcast read
-    const u32x4 ib = *(const u32x4*)(list + base + 8);
-    u32 x[16];
-    if (ablate & 1) {   // diagnostics: no mask-row loads
+  u32 t0, t1, t2, t3, f0, f1, e0, e1, s;
+  csa(t0, P[0], P[0], x[0], x[1]);
+  csa(t1, P[0], P[0], x[2], x[3]);
+  csa(f0, P[1], P[1], t0, t1);
+  csa(t2, P[0], P[0], x[4], x[5]);
+  csa(t3, P[0], P[0], x[6], x[7]);
+  csa(f1, P[1], P[1], t2, t3);
+  csa(e0, P[2], P[2], f0, f1);
+  csa(t0, P[0], P[0], x[8], x[9]);
+  csa(t1, P[0], P[0], x[10], x[11]);
+  csa(f0, P[1], P[1], t0, t1);
+  csa(t2, P[0], P[0], x[12], x[13]);
+  csa(t3, P[0], P[0], x[14], x[15]);
+  csa(f1, P[1], P[1], t2, t3);
+  csa(e1, P[2], P[2], f0, f1);
+  csa(s, P[3], P[3], e0, e1);
+  // ripple the weight-16 carry through the remaining planes
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        x[2 * j] = ia[j]; x[2 * j + 1] = ia[j] * 3u; x[8 + 2 * j] = ib[j]; x[8 + 2 * j + 1] = ib[j] * 5u;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        // row i of the tile starts i*256 bytes in (< 16 MB: a 32-bit offset); one v_perm_b32 turns a packed
-        // index into that offset: bytes {0, idx.lo, idx.hi, 0}
-        x[2 * j] = *(const u32*)((const char*)mt_lane + __builtin_amdgcn_perm(0u, ia[j], 0x0c01000cu));
-        x[2 * j + 1] = *(const u32*)((const char*)mt_lane + __builtin_amdgcn_perm(0u, ia[j], 0x0c03020cu));
-        x[8 + 2 * j] = *(const u32*)((const char*)mt_lane + __builtin_amdgcn_perm(0u, ib[j], 0x0c01000cu));
-        x[8 + 2 * j + 1] = *(const u32*)((const char*)mt_lane + __builtin_amdgcn_perm(0u, ib[j], 0x0c03020cu));
-      }
-    }
-    u32 t0, t1, t2, t3, f0, f1, e0, e1, s;
-    csa(t0, P[0], P[0], x[0], x[1]);
-    csa(t1, P[0], P[0], x[2], x[3]);
-    csa(f0, P[1], P[1], t0, t1);
-    csa(t2, P[0], P[0], x[4], x[5]);
-    csa(t3, P[0], P[0], x[6], x[7]);
-    csa(f1, P[1], P[1], t2, t3);
-    csa(e0, P[2], P[2], f0, f1);
-    csa(t0, P[0], P[0], x[8], x[9]);
-    csa(t1, P[0], P[0], x[10], x[11]);
-    csa(f0, P[1], P[1], t0, t1);
-    csa(t2, P[0], P[0], x[12], x[13]);
-    csa(t3, P[0], P[0], x[14], x[15]);
-    csa(f1, P[1], P[1], t2, t3);
-    csa(e1, P[2], P[2], f0, f1);
-    csa(s, P[3], P[3], e0, e1);
-    // ripple the weight-16 carry through the remaining planes
-#pragma unroll
-    for (int l = 4; l < L; l++) {
-      const u32 c = P[l] & s;
-      P[l] ^= s;
-      s = c;
-    }
+  for (int l = 4; l < L; l++) {
+    const u32 c = P[l] & s;
+    P[l] ^= s;
+    s = c;
   }
 }
 
@@ -149,9 +109,17 @@ __device__ __forceinline__ void transpose16(u32 (&R)[16]) {
 #undef GCRE_TSTAGE
 }
 
+constexpr int kDiagCap = 1024;   // table-diagonal entries staged in LDS per wave (longer diagonals are gathered from L2)
+
+// 16 mask rows addressed by 16 wave-uniform byte offsets (SGPRs): lane*4 is the vector offset
+__device__ __forceinline__ void load16(u32 (&x)[16], __amdgpu_buffer_rsrc_t mt, u32 lane4, const u32x16 offs) {
+#pragma unroll
+  for (int j = 0; j < 16; j++) x[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+}
+
 template <int L>
 __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseArgs a) {
-  __shared__ __attribute__((aligned(16))) u16 lists[kSparseWaves][kListCap];
+  __shared__ u32 diag_lds[kSparseWaves][kDiagCap];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Work items are (permutation tile kt, slice sl of the segment list), ordered kt-major.  Workgroups that share
@@ -162,16 +130,21 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
   const i64 wi = (i64)(blockIdx.x >> 3) * kSparseWaves + wave;       // wave index inside the XCD
   const i64 wx = a.waves_per_xcd;
   const i64 slices = 8 * wx;                                         // slices per permutation tile
-  u16* list = lists[wave];
-  const u32 zrow = a.mt_rows - 1;
-  const int nch = (a.W32p + 63) >> 6;
-  const SparseSeg* segs = (const SparseSeg*)a.segs;
+  const u32 lane4 = (u32)lane * 4u;
+  u32* dl = diag_lds[wave];
+
+  const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
+  const u64 GCRE_CONSTANT* loff0 = (const u64 GCRE_CONSTANT*)a.loff0;
+  const u32 GCRE_CONSTANT* lidx0 = (const u32 GCRE_CONSTANT*)a.lidx0;
+  const u64 GCRE_CONSTANT* doff = (const u64 GCRE_CONSTANT*)a.doff;
+  const u32 GCRE_CONSTANT* dlist = (const u32 GCRE_CONSTANT*)a.dlist;
+  const u32 GCRE_CONSTANT* tots = (const u32 GCRE_CONSTANT*)a.tot;
 
   u32 nmax[32];
 #pragma unroll
   for (int q = 0; q < 32; q++) nmax[q] = 0u;
   int cur_kt = -1;
-  const u32* mt_lane = a.mt + lane;
+  __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)a.mt, 0, 0x7fffffff, 0x00020000);
 
   auto flush = [&]() {
     if (cur_kt < 0) return;
@@ -183,79 +156,107 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
     }
   };
 
-  for (int step = 0; step < a.nkt; step++) {
-   const i64 item = (i64)xcd * a.nkt * wx + wi + (i64)step * wx;
-   const int kt = (int)(item / slices);
-   const i64 sl = item % slices;
-   if (kt != cur_kt) {
-     flush();
-     cur_kt = kt;
-     mt_lane = a.mt + (size_t)kt * a.mt_rows * 64 + lane;
-   }
-   for (i64 sidx = sl; sidx < a.nsegs; sidx += slices) {
-    const u32 row0 = __builtin_amdgcn_readfirstlane(segs[sidx].row0);
-    const u32 first = __builtin_amdgcn_readfirstlane(segs[sidx].first);
-    const u32 npaths = __builtin_amdgcn_readfirstlane(segs[sidx].n);
-    const u32* r0 = a.p0 + (size_t)row0 * a.S32;
-
-    // bits of the shared paths0 row -> base counters
-    u32 B[L];
+  // counters of one joined path -> 32 integers per lane -> table diagonal -> running maxima (methods.h:96-103)
+  auto finish_path = [&](u32 (&C)[L], u32 total) {
+    u32 R[16];
 #pragma unroll
-    for (int l = 0; l < L; l++) B[l] = 0u;
-    {
-      u32 nb = 0;
-      for (int c = 0; c < nch; c++) {
-        const int k = c * 64 + lane;
-        const u32 w = (k < a.W32p) ? r0[k] : 0u;
-        nb = append_list(list, nb, w, (u32)c, lane);
-        if (nb > kListFlush || c + 1 == nch) {
-          seal_list(list, nb, lane, zrow);
-          accumulate<L>(B, list, nb, mt_lane, a.ablate);
-          nb = 0;
-        }
-      }
-    }
-
-    for (u32 t = 0; t < npaths; t++) {
-      const u32 q = first + t;
-      const u32 r1row = __builtin_amdgcn_readfirstlane(a.row1[q]) & 0x7fffffffu;
-      const u32* r1 = a.p1 + (size_t)r1row * a.S32;
-      u32 C[L];
-#pragma unroll
-      for (int l = 0; l < L; l++) C[l] = B[l];
-      // only the bits paths1 adds on top of paths0
-      u32 nb = 0;
-      for (int c = 0; c < nch; c++) {
-        const int k = c * 64 + lane;
-        const u32 w = (k < a.W32p) ? (r1[k] & ~r0[k]) : 0u;
-        nb = append_list(list, nb, w, (u32)c, lane);
-        if (nb > kListFlush || c + 1 == nch) {
-          seal_list(list, nb, lane, zrow);
-          accumulate<L>(C, list, nb, mt_lane, a.ablate);
-          nb = 0;
-        }
-      }
-
-      // counters -> 32 integers per lane -> table diagonal -> running maxima (methods.h:96-103)
-      u32 R[16];
-#pragma unroll
-      for (int l = 0; l < 16; l++) R[l] = (l < L) ? C[l] : 0u;
-      transpose16(R);
-      const u32 total = __builtin_amdgcn_readfirstlane(a.tot[q]);
-      const char* diag = (const char*)((const u32*)a.t32 + sp_diag_offset(total));
+    for (int l = 0; l < 16; l++) R[l] = (l < L) ? C[l] : 0u;
+    transpose16(R);
+    const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(total);
+    if (total < (u32)kDiagCap) {
+      // the diagonal (total+1 cells) goes through LDS: a few coalesced loads instead of 32 64-address gathers
+      for (u32 i = (u32)lane; i <= total; i += 64) dl[i] = diag_g[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int j = 0; j < 16; j++) {
-        u32 lo, hi;
-        if (a.ablate & 2) { lo = R[j] & 0xffffu; hi = R[j] >> 16; }
-        else {
-          lo = *(const u32*)(diag + ((R[j] & 0xffffu) << 2));
-          hi = *(const u32*)(diag + ((R[j] >> 16) << 2));
-        }
+        const u32 lo = dl[R[j] & 0xffffu];
+        const u32 hi = dl[R[j] >> 16];
+        nmax[j] = (lo > nmax[j]) ? lo : nmax[j];
+        nmax[j + 16] = (hi > nmax[j + 16]) ? hi : nmax[j + 16];
+      }
+      __builtin_amdgcn_wave_barrier();   // the next path overwrites dl
+    } else {
+      for (int j = 0; j < 16; j++) {
+        const u32 lo = diag_g[R[j] & 0xffffu];
+        const u32 hi = diag_g[R[j] >> 16];
         nmax[j] = (lo > nmax[j]) ? lo : nmax[j];
         nmax[j + 16] = (hi > nmax[j + 16]) ? hi : nmax[j + 16];
       }
     }
-   }
+  };
+
+  for (int step = 0; step < a.nkt; step++) {
+    const i64 item = (i64)xcd * a.nkt * wx + wi + (i64)step * wx;
+    const int kt = (int)(item / slices);
+    const i64 sl = item % slices;
+    if (kt != cur_kt) {
+      flush();
+      cur_kt = kt;
+      mt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mt + (size_t)kt * a.mt_rows * 64), 0, 0x7fffffff, 0x00020000);
+    }
+    for (i64 sidx = sl; sidx < a.nsegs; sidx += slices) {
+      const u32 row0 = segs[sidx].row0;
+      const u32 first = segs[sidx].first;
+      const u32 npaths = segs[sidx].n;
+
+      // Both phases are streams of 16-entry blocks of wave-uniform row offsets.  The loads of block i+1 are in
+      // flight while block i goes through the adder tree (two register sets), so a wave keeps 16-32 mask-row
+      // loads outstanding instead of draining to zero between blocks.
+      u32 xa[16], xb[16];
+
+      // ---- bits of the shared paths0 row -> base counters ----
+      u32 B[L];
+#pragma unroll
+      for (int l = 0; l < L; l++) B[l] = 0u;
+      {
+        u64 p = loff0[row0];
+        const u64 e = loff0[row0 + 1];
+        if (p < e) load16(xa, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(lidx0 + p));
+        while (p < e) {
+          p += 16;
+          if (p < e) load16(xb, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(lidx0 + p));
+          add16<L>(B, xa);
+          if (p >= e) break;
+          p += 16;
+          if (p < e) load16(xa, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(lidx0 + p));
+          add16<L>(B, xb);
+        }
+      }
+
+      // ---- per joined path: the bits paths1 adds on top of paths0; the delta lists of a segment's paths are
+      // contiguous, so the block stream runs across path boundaries without draining ----
+      u64 p = doff[first];
+      const u64 e = doff[first + npaths];
+      u64 bound = doff[first + 1];           // end of the current path's blocks
+      u32 t = 0;
+      u32 C[L];
+#pragma unroll
+      for (int l = 0; l < L; l++) C[l] = B[l];
+      if (p < e) load16(xa, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(dlist + p));
+      bool in_a = true;                      // which register set holds block p
+      while (t < npaths) {
+        if (p == bound) {                    // all blocks of path t are in: finish it
+          finish_path(C, tots[first + t]);
+          t++;
+#pragma unroll
+          for (int l = 0; l < L; l++) C[l] = B[l];
+          if (t < npaths) bound = doff[first + t + 1];
+          continue;
+        }
+        const u64 pn = p + 16;
+        if (in_a) {
+          if (pn < e) load16(xb, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(dlist + pn));
+          add16<L>(C, xa);
+        } else {
+          if (pn < e) load16(xa, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(dlist + pn));
+          add16<L>(C, xb);
+        }
+        in_a = !in_a;
+        p = pn;
+      }
+    }
   }
   flush();
 }
@@ -267,6 +268,207 @@ hipError_t launch_null_sparse(const SparseArgs& a, int planes, hipStream_t strea
   else if (planes <= 10) hipLaunchKernelGGL(k_null_sparse<10>, grid, block, 0, stream, a);
   else if (planes <= 12) hipLaunchKernelGGL(k_null_sparse<12>, grid, block, 0, stream, a);
   else hipLaunchKernelGGL(k_null_sparse<16>, grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+int sparse_max_waves_per_cu(int planes) {
+  int blocks = 0;
+  hipError_t e;
+  if (planes <= 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_sparse<8>, 64 * kSparseWaves, 0);
+  else if (planes <= 10) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_sparse<10>, 64 * kSparseWaves, 0);
+  else if (planes <= 12) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_sparse<12>, 64 * kSparseWaves, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_sparse<16>, 64 * kSparseWaves, 0);
+  if (e != hipSuccess || blocks < 1) blocks = 1;
+  return blocks * kSparseWaves;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inspector: per joined path the list of bits that paths1 adds on top of paths0 (once per join, not per tile)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_delta_fill(const u32* p0, int S32, const u32* row0, const u32* row1, i64 count,
+                                                    const u64* loff1, const u32* lidx1, const u64* doff, u32 zoff,
+                                                    u32* dlist) {
+  const int lane = threadIdx.x & 63;
+  const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+  for (i64 i = wave; i < count; i += nwaves) {
+    const u32* r0 = p0 + (size_t)row0[i] * S32;
+    const u32 r1 = row1[i] & 0x7fffffffu;
+    const u64 b1 = loff1[r1], e1 = loff1[r1 + 1];
+    u64 out = doff[i];
+    const u64 out_end = doff[i + 1];
+    for (u64 p = b1; p < e1; p += 64) {
+      const u32 e = (p + lane < e1) ? lidx1[p + lane] : zoff;
+      const u32 idx = e >> 8;                                  // patient number
+      bool keep = (e != zoff);
+      const u32 w0 = keep ? r0[idx >> 5] : 0u;
+      keep = keep && (((w0 >> (idx & 31u)) & 1u) == 0u);
+      const u64 m = __ballot(keep);
+      const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+      if (keep) dlist[out + before] = e;
+      out += (u64)__builtin_popcountll(m);
+    }
+    if (out + lane < out_end) dlist[out + lane] = zoff;       // at most 15 padding entries
+  }
+}
+
+hipError_t launch_delta_fill(const uint32_t* p0, int S32, const uint32_t* row0, const uint32_t* row1, int64_t count,
+                             const uint64_t* loff1, const uint32_t* lidx1, const uint64_t* doff, uint32_t zoff,
+                             uint32_t* dlist, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  const i64 blocks = (count + 3) / 4;
+  hipLaunchKernelGGL(k_delta_fill, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream, p0, S32,
+                     row0, row1, count, loff1, lidx1, doff, zoff, dlist);
+  return hipGetLastError();
+}
+
+// exclusive scan of u32 counts into u64 offsets: per-1024 partial sums, one block scans them, then local scans
+__global__ __launch_bounds__(256) void k_scan_partial(const u32* cnt, i64 n, u64* part) {
+  __shared__ u64 red[4];
+  const i64 base = (i64)blockIdx.x * 1024;
+  u64 s = 0;
+  for (int k = threadIdx.x; k < 1024; k += 256)
+    if (base + k < n) s += cnt[base + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_top(u64* part, i64 nb) {
+  // single block: exclusive scan of nb partial sums in place; part[nb] receives the grand total
+  __shared__ u64 tmp[1024];
+  __shared__ u64 carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (i64 base = 0; base < nb; base += 1024) {
+    const i64 i = base + threadIdx.x;
+    const u64 v = (i < nb) ? part[i] : 0;
+    tmp[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const u64 add = (threadIdx.x >= (unsigned)o) ? tmp[threadIdx.x - o] : 0;
+      __syncthreads();
+      tmp[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nb) part[i] = carry + tmp[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += tmp[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[nb] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const u32* cnt, i64 n, const u64* part, u64* off) {
+  // one wave-serial pass per 1024 elements: 4 waves x 256 elements, sequential carry inside the block via LDS
+  __shared__ u64 wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const i64 base = (i64)blockIdx.x * 1024 + wave * 256;
+  u32 v[4];
+  u64 s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const i64 i = base + lane * 4 + k;
+    v[k] = (i < n) ? cnt[i] : 0u;
+    s += v[k];
+  }
+  // inclusive scan of the 64 per-lane sums
+  u64 incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u64 t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u64 pre = part[blockIdx.x];
+  for (int w = 0; w < wave; w++) pre += wsum[w];
+  u64 run = pre + incl - s;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const i64 i = base + lane * 4 + k;
+    if (i < n) off[i] = run;
+    run += v[k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) off[n] = part[gridDim.x];
+}
+
+hipError_t launch_scan_u32_u64(const uint32_t* cnt, int64_t n, uint64_t* off, uint64_t* scratch, hipStream_t stream) {
+  if (n <= 0) return hipMemsetAsync(off, 0, 8, stream);
+  const i64 nb = (n + 1023) / 1024;
+  hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(256), 0, stream, cnt, n, scratch);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, scratch, nb);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, cnt, n, scratch, off);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-row bit lists of a path set (CSR): entry = (patient index) << 8 = byte offset of the patient's row in a
+// mask tile; every row's list is padded with `zoff` (the all-zero row) to a multiple of 16 entries
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 sp_wave_sum(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_row_bits(const u32* rows, i64 nrows, int S32, int W32p, u32* cnt) {
+  const int lane = threadIdx.x & 63;
+  const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+  for (i64 r = wave; r < nrows; r += nwaves) {
+    const u32* row = rows + (size_t)r * S32;
+    u32 c = 0;
+    for (int k = lane; k < W32p; k += 64) c += __builtin_popcount(row[k]);
+    c = sp_wave_sum(c);
+    if (lane == 0) cnt[r] = (c + 15u) & ~15u;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_row_fill(const u32* rows, i64 nrows, int S32, int W32p, const u64* off,
+                                                  u32 zoff, u32* idx) {
+  const int lane = threadIdx.x & 63;
+  const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+  const int nch = (W32p + 63) >> 6;
+  for (i64 r = wave; r < nrows; r += nwaves) {
+    const u32* row = rows + (size_t)r * S32;
+    u64 pos = off[r];
+    const u64 end = off[r + 1];
+    for (int c = 0; c < nch; c++) {
+      const int k = c * 64 + lane;
+      u32 w = (k < W32p) ? row[k] : 0u;
+      const u32 cnt = __builtin_popcount(w);
+      const u32 incl = wave_scan_add(cnt);
+      u64 p = pos + incl - cnt;
+      const u32 base = (u32)c * 2048u + (u32)lane * 32u;
+      while (w) {
+        const u32 b = __builtin_ctz(w);
+        idx[p++] = (base + b) << 8;
+        w &= w - 1;
+      }
+      pos += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (pos + lane < end) idx[pos + lane] = zoff;   // at most 15 padding entries
+  }
+}
+
+hipError_t launch_row_bits(const uint32_t* rows, int64_t nrows, int S32, int W32p, uint32_t* cnt, hipStream_t stream) {
+  if (nrows == 0) return hipSuccess;
+  const i64 blocks = (nrows + 3) / 4;
+  hipLaunchKernelGGL(k_row_bits, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, rows, nrows, S32,
+                     W32p, cnt);
+  return hipGetLastError();
+}
+
+hipError_t launch_row_fill(const uint32_t* rows, int64_t nrows, int S32, int W32p, const uint64_t* off, uint32_t zoff,
+                           uint32_t* idx, hipStream_t stream) {
+  if (nrows == 0) return hipSuccess;
+  const i64 blocks = (nrows + 3) / 4;
+  hipLaunchKernelGGL(k_row_fill, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, rows, nrows, S32,
+                     W32p, off, zoff, idx);
   return hipGetLastError();
 }
 
