@@ -201,60 +201,34 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
       const u32 first = segs[sidx].first;
       const u32 npaths = segs[sidx].n;
 
-      // Both phases are streams of 16-entry blocks of wave-uniform row offsets.  The loads of block i+1 are in
-      // flight while block i goes through the adder tree (two register sets), so a wave keeps 16-32 mask-row
-      // loads outstanding instead of draining to zero between blocks.
-      u32 xa[16], xb[16];
+      // Both phases are streams of 16-entry blocks of wave-uniform row offsets (s_load_dwordx16 -> 16 scalar
+      // offsets -> 16 buffer loads -> adder tree).
+      u32 x[16];
 
       // ---- bits of the shared paths0 row -> base counters ----
       u32 B[L];
 #pragma unroll
       for (int l = 0; l < L; l++) B[l] = 0u;
       {
-        u64 p = loff0[row0];
         const u64 e = loff0[row0 + 1];
-        if (p < e) load16(xa, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(lidx0 + p));
-        while (p < e) {
-          p += 16;
-          if (p < e) load16(xb, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(lidx0 + p));
-          add16<L>(B, xa);
-          if (p >= e) break;
-          p += 16;
-          if (p < e) load16(xa, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(lidx0 + p));
-          add16<L>(B, xb);
+        for (u64 p = loff0[row0]; p < e; p += 16) {
+          load16(x, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(lidx0 + p));
+          add16<L>(B, x);
         }
       }
 
-      // ---- per joined path: the bits paths1 adds on top of paths0; the delta lists of a segment's paths are
-      // contiguous, so the block stream runs across path boundaries without draining ----
-      u64 p = doff[first];
-      const u64 e = doff[first + npaths];
-      u64 bound = doff[first + 1];           // end of the current path's blocks
-      u32 t = 0;
-      u32 C[L];
+      // ---- per joined path: the bits paths1 adds on top of paths0 (delta lists, built once per join) ----
+      for (u32 t = 0; t < npaths; t++) {
+        const u32 q = first + t;
+        u32 C[L];
 #pragma unroll
-      for (int l = 0; l < L; l++) C[l] = B[l];
-      if (p < e) load16(xa, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(dlist + p));
-      bool in_a = true;                      // which register set holds block p
-      while (t < npaths) {
-        if (p == bound) {                    // all blocks of path t are in: finish it
-          finish_path(C, tots[first + t]);
-          t++;
-#pragma unroll
-          for (int l = 0; l < L; l++) C[l] = B[l];
-          if (t < npaths) bound = doff[first + t + 1];
-          continue;
+        for (int l = 0; l < L; l++) C[l] = B[l];
+        const u64 e = doff[q + 1];
+        for (u64 p = doff[q]; p < e; p += 16) {
+          load16(x, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(dlist + p));
+          add16<L>(C, x);
         }
-        const u64 pn = p + 16;
-        if (in_a) {
-          if (pn < e) load16(xb, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(dlist + pn));
-          add16<L>(C, xa);
-        } else {
-          if (pn < e) load16(xa, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(dlist + pn));
-          add16<L>(C, xb);
-        }
-        in_a = !in_a;
-        p = pn;
+        finish_path(C, tots[q]);
       }
     }
   }

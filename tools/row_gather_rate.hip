@@ -1,0 +1,70 @@
+// tools/row_gather_rate.hip -- how fast can a CU pull random rows of a table that lives in L2 / Infinity Cache?
+// The sparse null kernel's mask-row loads are exactly this pattern: wave-uniform random row, lane*W bytes inside it.
+//   hipcc --offload-arch=gfx950 -O3 tools/row_gather_rate.hip -o tools/row_gather_rate && tools/row_gather_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef uint32_t u32;
+typedef u32 __attribute__((ext_vector_type(2))) u32x2;
+typedef u32 __attribute__((ext_vector_type(4))) u32x4;
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+// each wave: ITERS blocks of 16 random rows; row = 64 lanes x W dwords; xor-reduce so nothing is dead
+template <int W>
+__global__ __launch_bounds__(256) void k_rows(const u32* table, u32 nrows, u32* out, int iters, u32 seed) {
+  const int lane = threadIdx.x & 63;
+  const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6);
+  u32 s = seed ^ (wave * 2654435761u);
+  u32 acc[W];
+  for (int w = 0; w < W; w++) acc[w] = 0;
+  for (int it = 0; it < iters; it++) {
+    u32 rows[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { s = s * 1664525u + 1013904223u; rows[j] = __builtin_amdgcn_readfirstlane((s >> 8) % nrows); }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const u32* p = table + (size_t)rows[j] * 64 * W + lane * W;
+      if (W == 1) acc[0] ^= p[0];
+      else if (W == 2) { u32x2 v = *(const u32x2*)p; acc[0] ^= v.x; acc[1] ^= v.y; }
+      else { u32x4 v = *(const u32x4*)p; acc[0] ^= v.x; acc[1] ^= v.y; acc[2] ^= v.z; acc[3] ^= v.w; }
+    }
+  }
+  u32 r = 0;
+  for (int w = 0; w < W; w++) r ^= acc[w];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+template <int W>
+int run(u32 nrows, int blocks_per_cu, int iters) {
+  const size_t bytes = (size_t)nrows * 64 * W * 4;
+  u32 *table, *out;
+  CHECK(hipMalloc(&table, bytes)); CHECK(hipMemset(table, 1, bytes));
+  const int blocks = 256 * blocks_per_cu;
+  CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
+  hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  float ms = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL(k_rows<W>, dim3(blocks), dim3(256), 0, 0, table, nrows, out, iters, 12345u + rep);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    CHECK(hipEventElapsedTime(&ms, a, b));
+  }
+  const double loads = (double)blocks * 4 * iters * 16;
+  const double gb = loads * 64 * W * 4 / 1e9;
+  printf("row %4d B  table %6.1f MB  %2d waves/CU : %.3f ms  %.2f Gload/s  %.1f TB/s  %.1f B/clk/CU @2.3GHz\n", 64 * W * 4,
+         bytes / 1e6, blocks_per_cu * 4, ms, loads / ms / 1e6, gb / ms, gb / ms * 1e12 / 256 / 2.3e9 / 1e3 * 1e0);
+  hipFree(table); hipFree(out);
+  return 0;
+}
+
+int main() {
+  for (int bpc : {3, 5, 8}) {
+    for (u32 nrows : {5121u, 25605u}) {      // one tile (1.3 MB) / five tiles (6.5 MB) of 256-B rows
+      if (run<1>(nrows, bpc, 256)) return 1;
+      if (run<2>(nrows / 2, bpc, 256)) return 1;
+      if (run<4>(nrows / 4, bpc, 256)) return 1;
+    }
+  }
+  return 0;
+}
