@@ -193,9 +193,9 @@ gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
   return ps;
 }
 
-// The sparse kernel handles method 1 with patient indices that fit 16 bits; GCRE_NULL_KERNEL=dense turns it off.
+// The sparse kernel needs counts that fit 16 bits (64*Wp < 65535 patients); GCRE_NULL_KERNEL=dense turns it off.
 bool sparse_enabled(const gcre_ctx* c) {
-  return c->null_kernel != 1 && c->g.method == 1 && c->g.K > 0 && 64 * c->g.Wp < 65535;
+  return c->null_kernel != 1 && c->g.K > 0 && 64 * c->g.Wp < 65535;
 }
 
 int build_transposed_masks(gcre_ctx* c) {
@@ -222,11 +222,13 @@ void drop_lists(const gcre_pathset* ps) {
 int ensure_lists(gcre_ctx* c, const gcre_pathset* ps) {
   if (ps->d_loff) return GCRE_OK;
   const Geometry& g = c->g;
-  const int64_t n = ps->nrows;
+  // method 2: every row is two half-rows (+)/(-) of W32p dwords, stored back to back -> 2*nrows lists
+  const int64_t n = ps->nrows * g.method;
+  const int hs32 = 2 * g.Wp;   // dwords per half-row == stride between half-rows
   std::vector<uint32_t> cnt((size_t)std::max<int64_t>(n, 1), 0);
   uint32_t* d_cnt = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d_cnt, cnt.size() * 4));
-  hipError_t e = launch_row_bits((const uint32_t*)ps->d_rows, n, 2 * g.S, 2 * g.Wp, d_cnt, c->stream);
+  hipError_t e = launch_row_bits((const uint32_t*)ps->d_rows, n, hs32, hs32, d_cnt, c->stream);
   if (e == hipSuccess && n > 0) e = hipMemcpyAsync(cnt.data(), d_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d_cnt);
@@ -238,7 +240,7 @@ int ensure_lists(gcre_ctx* c, const gcre_pathset* ps) {
   HIP_TRY(c, hipMalloc((void**)&ps->d_lidx, (size_t)std::max<uint64_t>(total, 16) * 4));
   e = hipMemcpyAsync(ps->d_loff, off.data(), off.size() * 8, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess)
-    e = launch_row_fill((const uint32_t*)ps->d_rows, n, 2 * g.S, 2 * g.Wp, ps->d_loff, (uint32_t)(64 * g.Wp) << 8,
+    e = launch_row_fill((const uint32_t*)ps->d_rows, n, hs32, hs32, ps->d_loff, (uint32_t)(64 * g.Wp) << 8,
                         ps->d_lidx, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // off is a local
   if (e != hipSuccess) {
@@ -502,7 +504,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         if (use_sparse) {
           HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 4, st));
           sa.max_tot = c->d_max_tot;
-          HIP_TRY(c, c->d_dcnt.reserve((size_t)n));
+          HIP_TRY(c, c->d_dcnt.reserve((size_t)n * g.method));
           sa.dcnt = c->d_dcnt.p;
         }
         HIP_TRY(c, launch_stats(sa, g.method, st));
@@ -516,17 +518,19 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (int rc = ensure_lists(c, jp.p0)) return rc;
           if (int rc = ensure_lists(c, jp.p1)) return rc;
           const uint32_t zoff = (uint32_t)(64 * g.Wp) << 8;
-          HIP_TRY(c, c->d_doff.reserve((size_t)n + 1));
-          HIP_TRY(c, c->d_scan.reserve((size_t)(n + 1023) / 1024 + 2));
-          HIP_TRY(c, launch_scan_u32_u64(c->d_dcnt.p, n, c->d_doff.p, c->d_scan.p, st));
+          const int64_t nl = n * g.method;   // delta lists: one per joined path and half
+          HIP_TRY(c, c->d_doff.reserve((size_t)nl + 1));
+          HIP_TRY(c, c->d_scan.reserve((size_t)(nl + 1023) / 1024 + 2));
+          HIP_TRY(c, launch_scan_u32_u64(c->d_dcnt.p, nl, c->d_doff.p, c->d_scan.p, st));
           uint32_t max_tot = 0;
           uint64_t n_delta = 0;
           HIP_TRY(c, hipMemcpyAsync(&max_tot, c->d_max_tot, 4, hipMemcpyDeviceToHost, st));
-          HIP_TRY(c, hipMemcpyAsync(&n_delta, c->d_doff.p + n, 8, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(&n_delta, c->d_doff.p + nl, 8, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipStreamSynchronize(st));
           HIP_TRY(c, c->d_dlist.reserve((size_t)std::max<uint64_t>(n_delta, 16)));
-          HIP_TRY(c, launch_delta_fill((const uint32_t*)jp.p0->d_rows, 2 * g.S, c->d_row0.p, c->d_row1.p, n,
-                                       jp.p1->d_loff, jp.p1->d_lidx, c->d_doff.p, zoff, c->d_dlist.p, st));
+          HIP_TRY(c, launch_delta_fill((const uint32_t*)jp.p0->d_rows, 2 * g.S, 2 * g.Wp, g.method, c->d_row0.p,
+                                       c->d_row1.p, n, jp.p1->d_loff, jp.p1->d_lidx, c->d_doff.p, zoff,
+                                       c->d_dlist.p, st));
           int planes = 5;
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           SparseArgs sp{};
@@ -538,6 +542,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sp.doff = c->d_doff.p;
           sp.dlist = c->d_dlist.p;
           sp.t32 = c->d_t32;
+          sp.d64 = c->d_dmax;
           sp.null_bits = c->d_null;
           sp.nkt = (g.K + kSparseTile - 1) / kSparseTile;
           sp.mt_rows = (uint32_t)(64 * g.Wp + 1);
@@ -545,11 +550,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           int dev_cus = 256;
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
           if (const char* e = std::getenv("GCRE_SPARSE_ABLATE")) sp.ablate = std::atoi(e);
-          const int wpc = std::min(c->sparse_waves_per_cu, sparse_max_waves_per_cu(planes));
+          const int wpc = std::min(c->sparse_waves_per_cu, sparse_max_waves_per_cu(g.method, planes));
           sp.waves_per_xcd = std::max(4, (dev_cus * wpc / 8 / 4) * 4);
           hipEvent_t n0 = get_event(c), n1 = get_event(c);
           HIP_TRY(c, hipEventRecord(n0, st));
-          HIP_TRY(c, launch_null_sparse(sp, planes, st));
+          HIP_TRY(c, launch_null_sparse(sp, g.method, planes, st));
           HIP_TRY(c, hipEventRecord(n1, st));
           c->ev_null.emplace_back(n0, n1);
           c->prof.null_kernel_launches++;

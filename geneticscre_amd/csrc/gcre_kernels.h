@@ -74,7 +74,8 @@ struct SparseArgs {
   const uint32_t* lidx0;     // ... and entries = patient << 8 (byte offset of the patient's mask row), 16-padded
   const uint64_t* doff;      // per joined path of the launch: [count+1] offsets into dlist
   const uint32_t* dlist;     // entries of the bits paths1 adds on top of paths0, same encoding, 16-padded
-  const float* t32;
+  const float* t32;          // method 1 null table
+  const double* d64;         // method 2 null table (vtmax)
   uint32_t* null_bits;
   int64_t nsegs;
   int nkt;                   // 2048-permutation tiles
@@ -85,14 +86,14 @@ struct SparseArgs {
 };
 constexpr int kSparseTile = 2048;
 constexpr int kSparseSegMax = 64;
-hipError_t launch_null_sparse(const SparseArgs& a, int planes, hipStream_t stream);
-int sparse_max_waves_per_cu(int planes);   // resident waves per CU of the variant chosen for `planes` counter planes
+hipError_t launch_null_sparse(const SparseArgs& a, int method, int planes, hipStream_t stream);
+int sparse_max_waves_per_cu(int method, int planes);   // resident waves per CU of the variant chosen for `planes` counter planes
 // exclusive prefix sum of n u32 counts into n+1 u64 offsets (scratch: >= (n+1023)/1024 + 1 u64)
 hipError_t launch_scan_u32_u64(const uint32_t* cnt, int64_t n, uint64_t* off, uint64_t* scratch, hipStream_t stream);
 // per joined path: entries of paths1's list whose bit is clear in the paths0 row, 16-padded, at dlist[doff[i]..)
-hipError_t launch_delta_fill(const uint32_t* p0, int S32, const uint32_t* row0, const uint32_t* row1, int64_t count,
-                             const uint64_t* loff1, const uint32_t* lidx1, const uint64_t* doff, uint32_t zoff,
-                             uint32_t* dlist, hipStream_t stream);
+hipError_t launch_delta_fill(const uint32_t* p0, int S32, int W32p, int method, const uint32_t* row0,
+                             const uint32_t* row1, int64_t count, const uint64_t* loff1, const uint32_t* lidx1,
+                             const uint64_t* doff, uint32_t zoff, uint32_t* dlist, hipStream_t stream);
 hipError_t launch_row_bits(const uint32_t* rows, int64_t nrows, int S32, int W32p, uint32_t* cnt, hipStream_t stream);
 hipError_t launch_row_fill(const uint32_t* rows, int64_t nrows, int S32, int W32p, const uint64_t* off, uint32_t zoff,
                            uint32_t* idx, hipStream_t stream);

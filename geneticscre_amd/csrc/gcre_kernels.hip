@@ -492,11 +492,13 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
       const bool swap = (r1raw >> 31) != 0;
       const u64* yp = swap ? y + Wp : y;
       const u64* yn = swap ? y : y + Wp;
-      u32 case_pos = 0, ctrl_neg = 0, case_neg = 0, ctrl_pos = 0;
+      u32 case_pos = 0, ctrl_neg = 0, case_neg = 0, ctrl_pos = 0, dlp = 0, dln = 0;
       for (int k = lane; k < Wp; k += 64) {
         const u64 bp = x[k] | yp[k];            // methods.h:164-165
         const u64 bn = x[Wp + k] | yn[k];
         const u64 cm = a.case_mask[k];
+        dlp += __popcll(yp[k] & ~x[k]);         // sparse kernel: bits path1 adds to the (+) / (-) half
+        dln += __popcll(yn[k] & ~x[Wp + k]);
         case_pos += __popcll(bp & cm);          // methods.h:182-185
         ctrl_neg += __popcll(bp & ~cm);
         case_neg += __popcll(bn & ~cm);
@@ -507,6 +509,14 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
       ctrl_neg = wave_sum(ctrl_neg);
       case_neg = wave_sum(case_neg);
       ctrl_pos = wave_sum(ctrl_pos);
+      if (a.dcnt) {
+        dlp = wave_sum(dlp);
+        dln = wave_sum(dln);
+        if (lane == 0) {
+          a.dcnt[2 * i] = (dlp + 15u) & ~15u;
+          a.dcnt[2 * i + 1] = (dln + 15u) & ~15u;
+        }
+      }
       if (lane == 0) {
         const u32 tp = case_pos + ctrl_neg, tn = case_neg + ctrl_pos;
         // vt[case_pos][ctrl_neg] + vt[case_neg][ctrl_pos], methods.h:255

@@ -117,9 +117,14 @@ __device__ __forceinline__ void load16(u32 (&x)[16], __amdgpu_buffer_rsrc_t mt, 
   for (int j = 0; j < 16; j++) x[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
 }
 
-template <int L>
+constexpr int kDiagCap2 = 512;   // method 2: f64 cells staged per half
+
+// M = 1: one counter set per joined path (unsigned method, methods.h:58-105).
+// M = 2: the (+) and (-) halves are two independent sparse accumulations (methods.h:130-232); half h of joined
+//        path q uses list 2*q+h, half h of paths0 row r uses list 2*r+h.
+template <int M, int L>
 __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseArgs a) {
-  __shared__ u32 diag_lds[kSparseWaves][kDiagCap];
+  __shared__ __attribute__((aligned(8))) u32 diag_lds[kSparseWaves][kDiagCap];   // M=2: 2 x 256 doubles
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Work items are (permutation tile kt, slice sl of the segment list), ordered kt-major.  Workgroups that share
@@ -156,19 +161,27 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
     }
   };
 
-  // counters of one joined path -> 32 integers per lane -> table diagonal -> running maxima (methods.h:96-103)
-  auto finish_path = [&](u32 (&C)[L], u32 total) {
-    u32 R[16];
+  // counter planes -> 16 registers of packed 16-bit counts: permutation j in the low half, j+16 in the high half
+  auto to_counts = [&](const u32 (&C)[L], u32 (&R)[16]) {
 #pragma unroll
     for (int l = 0; l < 16; l++) R[l] = (l < L) ? C[l] : 0u;
     transpose16(R);
+  };
+  auto wave_lds_fence = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // method 1: counts -> f32 table diagonal -> running maxima (methods.h:96-103)
+  auto finish_m1 = [&](const u32 (&C)[L], u32 total) {
+    u32 R[16];
+    to_counts(C, R);
     const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(total);
     if (total < (u32)kDiagCap) {
       // the diagonal (total+1 cells) goes through LDS: a few coalesced loads instead of 32 64-address gathers
       for (u32 i = (u32)lane; i <= total; i += 64) dl[i] = diag_g[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_lds_fence();
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const u32 lo = dl[R[j] & 0xffffu];
@@ -187,6 +200,37 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
     }
   };
 
+  // method 2: vtmax[a][tp-a] + vtmax[tn-b][b] in f64, rounded to f32, clamped at the 0 the maxima start from
+  // (methods.h:220-230); a, b = counts of the (+) / (-) half
+  auto finish_m2 = [&](const u32 (&Cp)[L], const u32 (&Cn)[L], u32 tp, u32 tn) {
+    u32 Rp[16], Rn[16];
+    to_counts(Cp, Rp);
+    to_counts(Cn, Rn);
+    const double* dp = a.d64 + sp_diag_offset(tp);
+    const double* dn = a.d64 + sp_diag_offset(tn);
+    const bool staged = (tp < (u32)kDiagCap2 / 2) && (tn < (u32)kDiagCap2 / 2);
+    double* lp = (double*)dl;
+    double* ln = lp + kDiagCap2 / 2;
+    if (staged) {
+      for (u32 i = (u32)lane; i <= tp; i += 64) lp[i] = dp[i];
+      for (u32 i = (u32)lane; i <= tn; i += 64) ln[i] = dn[i];
+      wave_lds_fence();
+    }
+    auto one = [&](u32 ca, u32 cb, u32& m) {
+      const double s = staged ? (lp[ca] + ln[cb]) : (dp[ca] + dn[cb]);
+      float f = (float)s;
+      f = (f > 0.0f) ? f : 0.0f;
+      const u32 v = __float_as_uint(f);
+      m = (v > m) ? v : m;
+    };
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      one(Rp[j] & 0xffffu, Rn[j] & 0xffffu, nmax[j]);
+      one(Rp[j] >> 16, Rn[j] >> 16, nmax[j + 16]);
+    }
+    if (staged) __builtin_amdgcn_wave_barrier();
+  };
+
   for (int step = 0; step < a.nkt; step++) {
     const i64 item = (i64)xcd * a.nkt * wx + wi + (i64)step * wx;
     const int kt = (int)(item / slices);
@@ -201,57 +245,73 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
       const u32 first = segs[sidx].first;
       const u32 npaths = segs[sidx].n;
 
-      // Both phases are streams of 16-entry blocks of wave-uniform row offsets (s_load_dwordx16 -> 16 scalar
+      // Every phase is a stream of 16-entry blocks of wave-uniform row offsets (s_load_dwordx16 -> 16 scalar
       // offsets -> 16 buffer loads -> adder tree).
       u32 x[16];
-
-      // ---- bits of the shared paths0 row -> base counters ----
-      u32 B[L];
-#pragma unroll
-      for (int l = 0; l < L; l++) B[l] = 0u;
-      {
-        const u64 e = loff0[row0 + 1];
-        for (u64 p = loff0[row0]; p < e; p += 16) {
-          load16(x, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(lidx0 + p));
-          add16<L>(B, x);
+      auto stream = [&](u32 (&P)[L], const u32 GCRE_CONSTANT* list, u64 p, u64 e) {
+        for (; p < e; p += 16) {
+          load16(x, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(list + p));
+          add16<L>(P, x);
         }
+      };
+
+      // ---- bits of the shared paths0 row (each half for method 2) -> base counters ----
+      u32 B[M][L];
+#pragma unroll
+      for (int h = 0; h < M; h++) {
+#pragma unroll
+        for (int l = 0; l < L; l++) B[h][l] = 0u;
+        const u64 r = (u64)row0 * M + h;
+        stream(B[h], lidx0, loff0[r], loff0[r + 1]);
       }
 
       // ---- per joined path: the bits paths1 adds on top of paths0 (delta lists, built once per join) ----
       for (u32 t = 0; t < npaths; t++) {
         const u32 q = first + t;
-        u32 C[L];
+        u32 C[M][L];
 #pragma unroll
-        for (int l = 0; l < L; l++) C[l] = B[l];
-        const u64 e = doff[q + 1];
-        for (u64 p = doff[q]; p < e; p += 16) {
-          load16(x, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(dlist + p));
-          add16<L>(C, x);
+        for (int h = 0; h < M; h++) {
+#pragma unroll
+          for (int l = 0; l < L; l++) C[h][l] = B[h][l];
+          const u64 d = (u64)q * M + h;
+          stream(C[h], dlist, doff[d], doff[d + 1]);
         }
-        finish_path(C, tots[q]);
+        if constexpr (M == 1) finish_m1(C[0], tots[q]);
+        else finish_m2(C[0], C[M - 1], tots[2 * q], tots[2 * q + 1]);
       }
     }
   }
   flush();
 }
 
-hipError_t launch_null_sparse(const SparseArgs& a, int planes, hipStream_t stream) {
+#define GCRE_SPARSE_DISPATCH(EXPR)                         \
+  if (method == 1) {                                       \
+    if (planes <= 8) { EXPR(1, 8); }                       \
+    else if (planes <= 10) { EXPR(1, 10); }                \
+    else if (planes <= 12) { EXPR(1, 12); }                \
+    else { EXPR(1, 16); }                                  \
+  } else {                                                 \
+    if (planes <= 8) { EXPR(2, 8); }                       \
+    else if (planes <= 10) { EXPR(2, 10); }                \
+    else if (planes <= 12) { EXPR(2, 12); }                \
+    else { EXPR(2, 16); }                                  \
+  }
+
+hipError_t launch_null_sparse(const SparseArgs& a, int method, int planes, hipStream_t stream) {
   const dim3 grid((unsigned)(8 * a.waves_per_xcd / kSparseWaves));
   const dim3 block(64 * kSparseWaves);
-  if (planes <= 8) hipLaunchKernelGGL(k_null_sparse<8>, grid, block, 0, stream, a);
-  else if (planes <= 10) hipLaunchKernelGGL(k_null_sparse<10>, grid, block, 0, stream, a);
-  else if (planes <= 12) hipLaunchKernelGGL(k_null_sparse<12>, grid, block, 0, stream, a);
-  else hipLaunchKernelGGL(k_null_sparse<16>, grid, block, 0, stream, a);
+#define GCRE_LAUNCH(MM, LL) hipLaunchKernelGGL((k_null_sparse<MM, LL>), grid, block, 0, stream, a)
+  GCRE_SPARSE_DISPATCH(GCRE_LAUNCH)
+#undef GCRE_LAUNCH
   return hipGetLastError();
 }
 
-int sparse_max_waves_per_cu(int planes) {
+int sparse_max_waves_per_cu(int method, int planes) {
   int blocks = 0;
-  hipError_t e;
-  if (planes <= 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_sparse<8>, 64 * kSparseWaves, 0);
-  else if (planes <= 10) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_sparse<10>, 64 * kSparseWaves, 0);
-  else if (planes <= 12) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_sparse<12>, 64 * kSparseWaves, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_sparse<16>, 64 * kSparseWaves, 0);
+  hipError_t e = hipSuccess;
+#define GCRE_OCC(MM, LL) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_sparse<MM, LL>, 64 * kSparseWaves, 0)
+  GCRE_SPARSE_DISPATCH(GCRE_OCC)
+#undef GCRE_OCC
   if (e != hipSuccess || blocks < 1) blocks = 1;
   return blocks * kSparseWaves;
 }
@@ -259,18 +319,25 @@ int sparse_max_waves_per_cu(int planes) {
 // ------------------------------------------------------------------------------------------------
 // inspector: per joined path the list of bits that paths1 adds on top of paths0 (once per join, not per tile)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_delta_fill(const u32* p0, int S32, const u32* row0, const u32* row1, i64 count,
-                                                    const u64* loff1, const u32* lidx1, const u64* doff, u32 zoff,
-                                                    u32* dlist) {
+__global__ __launch_bounds__(256) void k_delta_fill(const u32* p0, int S32, int W32p, int M, const u32* row0,
+                                                    const u32* row1, i64 count, const u64* loff1, const u32* lidx1,
+                                                    const u64* doff, u32 zoff, u32* dlist) {
+  // one wave per (joined path, half): half h of the joined path takes half h (or 1-h when the relation flips the
+  // sign, methods.h:140-142) of the paths1 row and drops every bit already set in half h of the paths0 row
   const int lane = threadIdx.x & 63;
   const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
-  for (i64 i = wave; i < count; i += nwaves) {
-    const u32* r0 = p0 + (size_t)row0[i] * S32;
-    const u32 r1 = row1[i] & 0x7fffffffu;
-    const u64 b1 = loff1[r1], e1 = loff1[r1 + 1];
-    u64 out = doff[i];
-    const u64 out_end = doff[i + 1];
+  for (i64 w = wave; w < count * M; w += nwaves) {
+    const i64 i = w / M;
+    const int h = (int)(w % M);
+    const u32* r0 = p0 + (size_t)row0[i] * S32 + (size_t)h * W32p;
+    const u32 r1raw = row1[i];
+    const u32 r1 = r1raw & 0x7fffffffu;
+    const int h1 = (M == 2 && (r1raw >> 31)) ? 1 - h : h;
+    const u64 li = (u64)r1 * M + h1;
+    const u64 b1 = loff1[li], e1 = loff1[li + 1];
+    u64 out = doff[w];
+    const u64 out_end = doff[w + 1];
     for (u64 p = b1; p < e1; p += 64) {
       const u32 e = (p + lane < e1) ? lidx1[p + lane] : zoff;
       const u32 idx = e >> 8;                                  // patient number
@@ -286,13 +353,13 @@ __global__ __launch_bounds__(256) void k_delta_fill(const u32* p0, int S32, cons
   }
 }
 
-hipError_t launch_delta_fill(const uint32_t* p0, int S32, const uint32_t* row0, const uint32_t* row1, int64_t count,
-                             const uint64_t* loff1, const uint32_t* lidx1, const uint64_t* doff, uint32_t zoff,
-                             uint32_t* dlist, hipStream_t stream) {
+hipError_t launch_delta_fill(const uint32_t* p0, int S32, int W32p, int method, const uint32_t* row0,
+                             const uint32_t* row1, int64_t count, const uint64_t* loff1, const uint32_t* lidx1,
+                             const uint64_t* doff, uint32_t zoff, uint32_t* dlist, hipStream_t stream) {
   if (count == 0) return hipSuccess;
-  const i64 blocks = (count + 3) / 4;
+  const i64 blocks = (count * method + 3) / 4;
   hipLaunchKernelGGL(k_delta_fill, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream, p0, S32,
-                     row0, row1, count, loff1, lidx1, doff, zoff, dlist);
+                     W32p, method, row0, row1, count, loff1, lidx1, doff, zoff, dlist);
   return hipGetLastError();
 }
 

@@ -38,9 +38,12 @@ def test_appendix_b_golden(case):
             assert (s, (a, b)) in ids
 
 
+@pytest.mark.parametrize("kernel", ["sparse", "dense"])
 @pytest.mark.parametrize("method", ["method1", "method2"])
 @pytest.mark.parametrize("n_perm", [0, 3, 100, 130, 700])
-def test_process_paths_matches_oracle(method, n_perm):
+def test_process_paths_matches_oracle(method, n_perm, kernel, monkeypatch):
+    """Both forms of the null kernel (bit-sliced sparse: gcre_sparse.hip; dense AND+popcount: gcre_kernels.hip)."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", kernel)
     nc, nt = 37, 52   # patients not a multiple of 64, nCases != nControls
     p = make_problem(60, 150, nc, nt, n_perm, 5, method=method, top_k=9, seed=11 + n_perm,
                      table=small_table(nc, nt, 3))
@@ -58,10 +61,12 @@ def test_wide_masks_and_hypergeometric_table(method):
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
 
 
-@pytest.mark.parametrize("method,n_perm", [("method1", 1100), ("method2", 600)])
-def test_baseline_mask_width_full_parity(method, n_perm):
+@pytest.mark.parametrize("kernel", ["sparse", "dense"])
+@pytest.mark.parametrize("method,n_perm", [("method1", 1100), ("method2", 600), ("method1", 2500)])
+def test_baseline_mask_width_full_parity(method, n_perm, kernel, monkeypatch):
     """BASELINE configs[2] geometry (5,000 patients = 79 mask words, real -log hypergeometric table, K not a
     multiple of the permutation tile) on a network small enough for the oracle: every level bit-exact."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", kernel)
     p = make_problem(220, 800, 2500, 2500, n_perm, 4, method=method, top_k=50, seed=77)
     want = oracle.process_paths(p, order="canonical", nthreads=8)
     got = api.process_paths(p)
@@ -95,3 +100,17 @@ def test_full_size_properties_without_oracle():
         pv = a[k].pvalues()
         assert (np.diff(pv) <= 0).all()        # ascending scores -> non-increasing p-values
     assert plan.uids["4"].total_paths > 200000
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_dense_rows_through_the_sparse_kernel(method, monkeypatch):
+    """The sparse kernel must stay exact when the data is not sparse at all: half of all patients carry every gene
+    (long bit lists, counter planes beyond 8, table diagonals too long for the LDS staging)."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "sparse")
+    p = make_problem(30, 70, 700, 900, 300, 4, method=method, top_k=11, seed=88, threshold=0.6)
+    rng = np.random.default_rng(5)
+    p.data1 = (rng.random(p.data1.shape) < 0.45).astype(np.int32)
+    p.data2 = p.data1[p.levels.uids["1b"].src]
+    got, want = run_both(p)
+    for lvl in range(1, 5):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
