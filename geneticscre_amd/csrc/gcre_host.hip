@@ -237,7 +237,7 @@ int ensure_lists(gcre_ctx* c, const gcre_pathset* ps) {
   for (int64_t r = 0; r < n; r++) off[(size_t)r + 1] = off[(size_t)r] + cnt[(size_t)r];
   const uint64_t total = off[(size_t)n];
   HIP_TRY(c, hipMalloc((void**)&ps->d_loff, off.size() * 8));
-  HIP_TRY(c, hipMalloc((void**)&ps->d_lidx, (size_t)std::max<uint64_t>(total, 16) * 4));
+  HIP_TRY(c, hipMalloc((void**)&ps->d_lidx, (size_t)(total + 16) * 4));
   e = hipMemcpyAsync(ps->d_loff, off.data(), off.size() * 8, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess)
     e = launch_row_fill((const uint32_t*)ps->d_rows, n, hs32, hs32, ps->d_loff, (uint32_t)(64 * g.Wp) << 8,
@@ -527,7 +527,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hipMemcpyAsync(&max_tot, c->d_max_tot, 4, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipMemcpyAsync(&n_delta, c->d_doff.p + nl, 8, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipStreamSynchronize(st));
-          HIP_TRY(c, c->d_dlist.reserve((size_t)std::max<uint64_t>(n_delta, 16)));
+          HIP_TRY(c, c->d_dlist.reserve((size_t)n_delta + 16));
           HIP_TRY(c, launch_delta_fill((const uint32_t*)jp.p0->d_rows, 2 * g.S, 2 * g.Wp, g.method, c->d_row0.p,
                                        c->d_row1.p, n, jp.p1->d_loff, jp.p1->d_lidx, c->d_doff.p, zoff,
                                        c->d_dlist.p, st));

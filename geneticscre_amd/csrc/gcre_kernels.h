@@ -71,9 +71,9 @@ struct SparseArgs {
   const uint32_t* tot;       // carriers per joined path of the launch
   const SparseSeg* segs;
   const uint64_t* loff0;     // CSR bit lists of paths0: offsets [rows+1] ...
-  const uint32_t* lidx0;     // ... and entries = patient << 8 (byte offset of the patient's mask row), 16-padded
+  const uint32_t* lidx0;     // ... and entries = patient << 8 (byte offset of the patient's mask row), 4-padded
   const uint64_t* doff;      // per joined path of the launch: [count+1] offsets into dlist
-  const uint32_t* dlist;     // entries of the bits paths1 adds on top of paths0, same encoding, 16-padded
+  const uint32_t* dlist;     // entries of the bits paths1 adds on top of paths0, same encoding, 4-padded
   const float* t32;          // method 1 null table
   const double* d64;         // method 2 null table (vtmax)
   uint32_t* null_bits;
@@ -126,7 +126,7 @@ struct StatsArgs {
   uint32_t* ctrls;
   uint64_t* res;               // kept rows, indexed by absolute ordinal (first + i), or nullptr
   uint32_t* max_tot;           // optional: running maximum of the carrier totals (sizes the sparse kernel's counters)
-  uint32_t* dcnt;              // optional (method 1): popcount(path1 & ~path0) rounded up to 16, per joined path
+  uint32_t* dcnt;              // optional (method 1): popcount(path1 & ~path0) rounded up to 4, per joined path (and half)
   int64_t first;
   int64_t count;
   int S;

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
       ct = wave_sum(ct);
       if (a.dcnt) {
         dl = wave_sum(dl);
-        if (lane == 0) a.dcnt[i] = (dl + 15u) & ~15u;
+        if (lane == 0) a.dcnt[i] = (dl + 3u) & ~3u;
       }
       if (lane == 0) {
         const u32 total = cs + ct;
@@ -513,8 +513,8 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
         dlp = wave_sum(dlp);
         dln = wave_sum(dln);
         if (lane == 0) {
-          a.dcnt[2 * i] = (dlp + 15u) & ~15u;
-          a.dcnt[2 * i + 1] = (dln + 15u) & ~15u;
+          a.dcnt[2 * i] = (dlp + 3u) & ~3u;
+          a.dcnt[2 * i + 1] = (dln + 3u) & ~3u;
         }
       }
       if (lane == 0) {

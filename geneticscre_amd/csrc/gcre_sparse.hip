@@ -33,6 +33,7 @@ namespace gcre {
 typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int64_t i64;
+typedef u32 __attribute__((ext_vector_type(4))) u32x4;
 typedef u32 __attribute__((ext_vector_type(16))) u32x16;
 
 #define GCRE_CONSTANT __attribute__((address_space(4)))
@@ -85,6 +86,21 @@ __device__ __forceinline__ void add16(u32 (&P)[L], const u32 (&x)[16]) {
   // ripple the weight-16 carry through the remaining planes
 #pragma unroll
   for (int l = 4; l < L; l++) {
+    const u32 c = P[l] & s;
+    P[l] ^= s;
+    s = c;
+  }
+}
+
+// Add 4 mask rows: the tail of a list (lists are padded to 4 entries, so at most 3 loads are wasted per list).
+template <int L>
+__device__ __forceinline__ void add4(u32 (&P)[L], const u32 (&x)[4]) {
+  u32 t0, t1, s;
+  csa(t0, P[0], P[0], x[0], x[1]);
+  csa(t1, P[0], P[0], x[2], x[3]);
+  csa(s, P[1], P[1], t0, t1);
+#pragma unroll
+  for (int l = 2; l < L; l++) {
     const u32 c = P[l] & s;
     P[l] ^= s;
     s = c;
@@ -249,9 +265,16 @@ __global__ __launch_bounds__(64 * kSparseWaves) void k_null_sparse(const SparseA
       // offsets -> 16 buffer loads -> adder tree).
       u32 x[16];
       auto stream = [&](u32 (&P)[L], const u32 GCRE_CONSTANT* list, u64 p, u64 e) {
-        for (; p < e; p += 16) {
+        for (; p + 16 <= e; p += 16) {
           load16(x, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(list + p));
           add16<L>(P, x);
+        }
+        for (; p < e; p += 4) {          // tail: blocks of 4 (the mask-row loads are what bounds this kernel)
+          const u32x4 offs = *(const u32x4 GCRE_CONSTANT*)(list + p);
+          u32 y[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) y[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+          add4<L>(P, y);
         }
       };
 
@@ -349,7 +372,7 @@ __global__ __launch_bounds__(256) void k_delta_fill(const u32* p0, int S32, int 
       if (keep) dlist[out + before] = e;
       out += (u64)__builtin_popcountll(m);
     }
-    if (out + lane < out_end) dlist[out + lane] = zoff;       // at most 15 padding entries
+    if (out + lane < out_end) dlist[out + lane] = zoff;       // at most 3 padding entries
   }
 }
 
@@ -447,7 +470,7 @@ hipError_t launch_scan_u32_u64(const uint32_t* cnt, int64_t n, uint64_t* off, ui
 
 // ------------------------------------------------------------------------------------------------
 // per-row bit lists of a path set (CSR): entry = (patient index) << 8 = byte offset of the patient's row in a
-// mask tile; every row's list is padded with `zoff` (the all-zero row) to a multiple of 16 entries
+// mask tile; every row's list is padded with `zoff` (the all-zero row) to a multiple of 4 entries
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 sp_wave_sum(u32 v) {
 #pragma unroll
@@ -464,7 +487,7 @@ __global__ __launch_bounds__(256) void k_row_bits(const u32* rows, i64 nrows, in
     u32 c = 0;
     for (int k = lane; k < W32p; k += 64) c += __builtin_popcount(row[k]);
     c = sp_wave_sum(c);
-    if (lane == 0) cnt[r] = (c + 15u) & ~15u;
+    if (lane == 0) cnt[r] = (c + 3u) & ~3u;
   }
 }
 
@@ -492,7 +515,7 @@ __global__ __launch_bounds__(256) void k_row_fill(const u32* rows, i64 nrows, in
       }
       pos += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (pos + lane < end) idx[pos + lane] = zoff;   // at most 15 padding entries
+    if (pos + lane < end) idx[pos + lane] = zoff;   // at most 3 padding entries
   }
 }
 
