@@ -35,6 +35,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9        # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops/s (32-bit integer VALU)
+ROW_LOAD_PEAK_G = 42.0                      # G wave-loads/s of random 256-B L2-resident rows (tools/row_gather_rate.hip)
 
 
 def build_inputs(cfg, seed, top_k):
@@ -203,15 +204,34 @@ def main():
     alg_bytes = prof_acc.get("null_alg_bytes", 0.0)
     my_scores = prof_acc.get("scores", 0)
     achieved = alg_bytes / 1e9 / null_s if null_s > 0 else 0.0
-    valu_ops = my_scores * 4.0 * W * M            # 2 x (v_and_b32 + v_bcnt_u32_b32) per 64-bit word per score
+    row_loads = prof_acc.get("null_row_loads", 0.0)
     roofline = {
-        "bound": "hbm", "kernel": "k_null", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
         "launches": launches, "avg_launch_ms": null_s * 1e3 / launches, "alg_bytes_per_launch": alg_bytes / launches,
-        "note": "north-star accounting (algorithmic HBM bytes / kernel time); the kernel is integer-VALU bound, see valu",
-        "valu": {"achieved": valu_ops / null_s / 1e12 if null_s > 0 else 0.0, "peak": VALU_PEAK_OPS / 1e12,
-                 "unit": "Tlane-op/s", "frac": (valu_ops / null_s / VALU_PEAK_OPS) if null_s > 0 else 0.0},
     }
+    # HBM traffic per launch from the committed PMC passes of this workload (profiles/), when there is one
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")))
+        if pmc.get("workload") == args.config and not args.edges and not args.perms and row_loads > 0 and world == 1:
+            roofline["traffic"] = pmc["traffic_bytes_per_null_launch"]
+            roofline["traffic_source"] = "profiles/r01_b_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, raw)"
+    except (OSError, ValueError, KeyError):
+        pass
+    if row_loads > 0:
+        # sparse bit-sliced kernel: bound by the rate at which a CU pulls random 256-byte mask rows out of L2
+        # (tools/row_gather_rate.hip measures ~40 G wave-loads/s on this chip), not by HBM and not by the VALU
+        roofline["kernel"] = "k_null_sparse"
+        roofline["note"] = ("north-star accounting (algorithmic HBM bytes / kernel time); the binding resource is the "
+                            "L2->L1 mask-row load rate, see rows")
+        roofline["rows"] = {"achieved": row_loads / null_s / 1e9 if null_s > 0 else 0.0, "peak": ROW_LOAD_PEAK_G,
+                            "unit": "G wave-loads/s", "frac": (row_loads / null_s / 1e9 / ROW_LOAD_PEAK_G) if null_s > 0 else 0.0}
+    else:
+        valu_ops = my_scores * 4.0 * W * M        # 2 x (v_and_b32 + v_bcnt_u32_b32) per 64-bit word per score
+        roofline["kernel"] = "k_null"
+        roofline["note"] = "north-star accounting (algorithmic HBM bytes / kernel time); the kernel is integer-VALU bound, see valu"
+        roofline["valu"] = {"achieved": valu_ops / null_s / 1e12 if null_s > 0 else 0.0, "peak": VALU_PEAK_OPS / 1e12,
+                            "unit": "Tlane-op/s", "frac": (valu_ops / null_s / VALU_PEAK_OPS) if null_s > 0 else 0.0}
 
     line = {
         "metric": "path_x_permutation_scores_per_sec", "value": value, "unit": "scores/s", "n_gpus": world,

@@ -40,7 +40,8 @@ class gcre_join_opts(ctypes.Structure):
 class gcre_profile(ctypes.Structure):
     _fields_ = [("null_kernel_ms", ctypes.c_double), ("null_kernel_launches", ctypes.c_int64),
                 ("stats_kernel_ms", ctypes.c_double), ("select_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
-                ("paths", ctypes.c_int64), ("scores", ctypes.c_int64), ("null_alg_bytes", ctypes.c_double)]
+                ("paths", ctypes.c_int64), ("scores", ctypes.c_int64), ("null_alg_bytes", ctypes.c_double),
+                ("null_row_loads", ctypes.c_double)]
 
 
 class gcre_level(ctypes.Structure):

@@ -103,6 +103,7 @@ struct gcre_pathset {
   // CSR bit lists for the sparse kernel, built on first use and dropped whenever the rows are rewritten
   mutable uint64_t* d_loff = nullptr;
   mutable uint32_t* d_lidx = nullptr;
+  mutable std::vector<uint64_t> h_loff;   // host copy of the offsets (sizes the work of a sparse launch)
 };
 
 // UidRelSet (src/gcre.h:49-90) resident on the device: prefix sums of count, locations, signs
@@ -175,7 +176,7 @@ gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
     fail(c, GCRE_ERR_RANGE, "path set too large for 32-bit row addressing");
     return nullptr;
   }
-  auto* ps = new gcre_pathset{c, nrows, nullptr, nullptr, nullptr};
+  auto* ps = new gcre_pathset{c, nrows, nullptr, nullptr, nullptr, {}};
   const size_t bytes = (size_t)std::max<int64_t>(nrows, 1) * c->g.S * sizeof(uint64_t);
   if (hipMalloc((void**)&ps->d_rows, bytes) != hipSuccess) {
     fail(c, GCRE_ERR_DEVICE, "hipMalloc failed for a path set of " + std::to_string(bytes) + " bytes");
@@ -216,6 +217,7 @@ void drop_lists(const gcre_pathset* ps) {
   if (ps->d_lidx) (void)hipFree(ps->d_lidx);
   ps->d_loff = nullptr;
   ps->d_lidx = nullptr;
+  ps->h_loff.clear();
 }
 
 // CSR bit lists of a path set (method 1: one list per row): offsets on the host by prefix sum, entries on the device
@@ -247,6 +249,7 @@ int ensure_lists(gcre_ctx* c, const gcre_pathset* ps) {
     drop_lists(ps);
     return fail(c, GCRE_ERR_DEVICE, std::string("row lists: ") + hipGetErrorString(e));
   }
+  ps->h_loff = std::move(off);
   return GCRE_OK;
 }
 
@@ -469,6 +472,22 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     HIP_TRY(c, c->d_ctrls.reserve(cap));
     HIP_TRY(c, c->d_key.reserve(cap));
 
+    // uids (rows of paths0) with at least one joined path inside [first, first+count)
+    auto uids_in = [&](int64_t first, int64_t count) {
+      const auto& pi = u.h_path_idx;
+      int64_t lo = std::upper_bound(pi.begin(), pi.end(), first) - pi.begin() - 1;
+      int64_t hi = std::lower_bound(pi.begin(), pi.end(), first + count) - pi.begin();   // first uid starting at/after the end
+      int64_t cnt = 0;
+      for (int64_t i = std::max<int64_t>(lo, 0); i < std::min(hi, u.n_uids); i++)
+        if (pi[(size_t)i + 1] > pi[(size_t)i]) cnt++;
+      return cnt;
+    };
+    // compulsory HBM bytes of the permutation scoring of `count` joined paths: every paths0 row
+    // once per uid, every paths1 row once per joined path, the masks and the maxima once, the join index
+    auto alg_bytes = [&](int64_t first, int64_t count) {
+      const double up = (double)uids_in(first, count);
+      return 8.0 * g.W * g.method * (up + (double)count) + 8.0 * g.W * g.K + 4.0 * g.K + 24.0 * up;
+    };
     for (const Seg& sg : segs) {
       for (int64_t cb = sg.b; cb < sg.e; cb += chunk_cap) {
         const int64_t n = std::min(chunk_cap, sg.e - cb);
@@ -547,6 +566,21 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sp.nkt = (g.K + kSparseTile - 1) / kSparseTile;
           sp.mt_rows = (uint32_t)(64 * g.Wp + 1);
           sp.zoff = zoff;
+          {
+            // mask-row loads of this launch: every segment walks its paths0 list(s) once, every joined path its
+            // delta list(s), for each permutation tile
+            const auto& pi = u.h_path_idx;
+            const auto& lo = jp.p0->h_loff;
+            double base_entries = 0;
+            int64_t i = std::upper_bound(pi.begin(), pi.end(), cb) - pi.begin() - 1;
+            for (; i < u.n_uids && pi[(size_t)i] < cb + n; i++) {
+              const int64_t a0 = std::max(pi[(size_t)i], cb), a1 = std::min(pi[(size_t)i + 1], cb + n);
+              if (a1 <= a0) continue;
+              const double segs_here = (double)((a1 - a0 + kSparseSegMax - 1) / kSparseSegMax);
+              base_entries += segs_here * (double)(lo[(size_t)(i + 1) * g.method] - lo[(size_t)i * g.method]);
+            }
+            c->prof.null_row_loads += (base_entries + (double)n_delta) * sp.nkt;
+          }
           int dev_cus = 256;
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
           if (const char* e = std::getenv("GCRE_SPARSE_ABLATE")) sp.ablate = std::atoi(e);
@@ -558,8 +592,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hipEventRecord(n1, st));
           c->ev_null.emplace_back(n0, n1);
           c->prof.null_kernel_launches++;
-          c->prof.null_alg_bytes += (double)n * (2.0 * g.S * 8 + 8.0 + 4.0 * g.method) +
-                                    (double)(2 * g.Wp) * g.K * 4.0 + (double)g.K * 4.0;
+          c->prof.null_alg_bytes += alg_bytes(cb, n);
         } else if (g.K > 0) {
           NullArgs na{};
           na.p0 = (const uint32_t*)jp.p0->d_rows;
@@ -589,10 +622,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hipEventRecord(n1, st));
           c->ev_null.emplace_back(n0, n1);
           c->prof.null_kernel_launches++;
-          // algorithmic bytes of this launch (DESIGN.md "Roofline accounting"): both operand rows of every
-          // joined path once, the mask block once, the row/total side arrays, the null maxima
-          c->prof.null_alg_bytes += (double)n * (2.0 * g.S * 8 + 8.0 + 4.0 * g.method) +
-                                    (double)(2 * g.Wp) * g.K * 4.0 + (double)g.K * 4.0;
+          c->prof.null_alg_bytes += alg_bytes(cb, n);
         }
 
         // ---- top-k of this chunk ----
@@ -1096,6 +1126,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     total.paths += c->prof.paths;
     total.scores += c->prof.scores;
     total.null_alg_bytes += c->prof.null_alg_bytes;
+    total.null_row_loads += c->prof.null_row_loads;
   };
 
   int rc = gcre_set_value_table(c, in->value_table, in->vt_rows, in->vt_cols, in->vt_col_major);   // wrapper.cpp:213

@@ -69,6 +69,7 @@ typedef struct {
   int64_t paths;              /* joined paths scored on this device */
   int64_t scores;             /* paths x iterations */
   double null_alg_bytes;      /* algorithmic HBM bytes of the null kernel launches */
+  double null_row_loads;      /* sparse kernel: mask-row loads issued (list entries x permutation tiles); 0 = dense kernel */
 } gcre_profile;
 
 /* ---- context: JoinExec::JoinExec, src/join_base.cpp:37-59.  method 1 = unsigned, 2 = signed. ---- */
