@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--top-k", type=int, default=100)
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + several ranks on one GPU is a rehearsal of the N > 1 path, not a measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,10 +144,14 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU fallback")
+    local_rank %= max(torch.cuda.device_count(), 1)      # rehearsal: several ranks may share the one GPU of a test box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     cfg = dict(CONFIGS[args.config])
     if args.edges:
@@ -165,9 +171,15 @@ def main():
         if world == 1:
             return r
         # RCCL: MAX all-reduce of the null maxima + all-gather/merge of the top-k tables (geneticscre_amd/dist.py)
-        best = exchange_level(r.scores, r.src, r.trg, r.cases, r.ctrls, d_null, top_k, world, device=dev)
+        if args.backend == "gloo":   # CPU collectives: stage the maxima through host memory
+            h_null = d_null.cpu()
+            best = exchange_level(r.scores, r.src, r.trg, r.cases, r.ctrls, h_null, top_k, world)
+            null = h_null[:K].numpy()
+        else:
+            best = exchange_level(r.scores, r.src, r.trg, r.cases, r.ctrls, d_null, top_k, world, device=dev)
+            null = d_null[:K].cpu().numpy()
         return api.JoinResult(best[:, 0].copy(), best[:, 1].astype(np.int32), best[:, 2].astype(np.int32),
-                              best[:, 3].astype(np.int32), best[:, 4].astype(np.int32), d_null[:K].cpu().numpy())
+                              best[:, 3].astype(np.int32), best[:, 4].astype(np.int32), null)
 
     def step():
         out = plan.run(rank, world, d_null_out=d_null.data_ptr(), on_level=on_level)
@@ -189,7 +201,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -253,6 +265,15 @@ def main():
             line["cpu_baseline"] = cpu_baseline(prob, masks)
         except Exception as e:   # the baseline is reported, never required
             line["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0 and os.environ.get("GCRE_BENCH_DUMP"):
+        # digest of the last step's results, for comparing runs with different rank counts
+        import hashlib
+        h = hashlib.sha256()
+        for name in plan.names:
+            r = last[name]
+            for arr in (r.scores, r.src, r.trg, r.cases, r.ctrls, r.null):
+                h.update(np.ascontiguousarray(arr).tobytes())
+        line["result_sha256"] = h.hexdigest()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

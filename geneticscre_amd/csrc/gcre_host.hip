@@ -531,7 +531,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         c->ev_stats.emplace_back(e0, e1);
         if (!sg.score) continue;
 
-        if (g.K > 0 && use_sparse) {
+        bool ran_sparse = false;
+        if (g.K > 0 && use_sparse) do {
           // inspector (once per chunk, shared by all permutation tiles): per joined path the bits paths1 adds
           // on top of paths0 -> offsets by a device scan of the counts k_stats left, entries by k_delta_fill
           if (int rc = ensure_lists(c, jp.p0)) return rc;
@@ -546,6 +547,16 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hipMemcpyAsync(&max_tot, c->d_max_tot, 4, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipMemcpyAsync(&n_delta, c->d_doff.p + nl, 8, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipStreamSynchronize(st));
+          if (c->null_kernel == 0) {
+            // auto: price both forms for this chunk (DESIGN.md "Kernel choice").  Sparse: one mask-row load per list
+            // entry per 2048-permutation tile at ~15 CU-cycles each; dense: 2 VALU ops per dword per permutation at
+            // ~65 lane-ops/clk/CU.  Base lists are bounded by the largest carrier total, once per segment.
+            const int64_t nseg_est = std::max<int64_t>(uids_in(cb, n), 1);
+            const double entries = (double)n_delta / (double)n + (double)max_tot * g.method * (double)nseg_est / (double)n;
+            const double sparse_cost = entries * ((g.K + kSparseTile - 1) / kSparseTile) * 15.0;
+            const double dense_cost = 2.0 * g.Wp * g.method * (double)g.K * 2.0 / 65.0;
+            if (sparse_cost >= dense_cost) break;   // dense kernel below
+          }
           HIP_TRY(c, c->d_dlist.reserve((size_t)n_delta + 16));
           HIP_TRY(c, launch_delta_fill((const uint32_t*)jp.p0->d_rows, 2 * g.S, 2 * g.Wp, g.method, c->d_row0.p,
                                        c->d_row1.p, n, jp.p1->d_loff, jp.p1->d_lidx, c->d_doff.p, zoff,
@@ -593,7 +604,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           c->ev_null.emplace_back(n0, n1);
           c->prof.null_kernel_launches++;
           c->prof.null_alg_bytes += alg_bytes(cb, n);
-        } else if (g.K > 0) {
+          ran_sparse = true;
+        } while (false);
+        if (g.K > 0 && !ran_sparse) {
           NullArgs na{};
           na.p0 = (const uint32_t*)jp.p0->d_rows;
           na.p1 = (const uint32_t*)jp.p1->d_rows;

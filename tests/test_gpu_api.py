@@ -153,3 +153,29 @@ def test_r_list_shape_and_pvalues():
     want = [(r.null.astype(np.float64) >= s).mean() for s in r.scores]
     np.testing.assert_array_equal(pv, np.array(want))
     assert (np.diff(r.scores) >= 0).all()
+
+
+def test_bench_two_ranks_reproduce_one_rank(tmp_path):
+    """bench.py's N > 1 path rehearsed on the one GPU of the test box: two ranks (gloo collectives, both on cuda:0)
+    shard every level, exchange null maxima and top-k tables, and must reproduce the one-rank results bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GCRE_BENCH_DUMP="1", GCRE_QUIET="1")
+    common = ["--no-cpu-baseline", "--steps", "1", "--warmup", "0", "--config", "subgraph", "--edges", "20000",
+              "--perms", "2500", "--top-k", "25"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True,
+                         env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", *common], capture_output=True, text=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2
+    assert a["result_sha256"] == b["result_sha256"]
+    assert a["config"]["scores_per_step"] == b["config"]["scores_per_step"]

@@ -38,7 +38,7 @@ def test_appendix_b_golden(case):
             assert (s, (a, b)) in ids
 
 
-@pytest.mark.parametrize("kernel", ["sparse", "dense"])
+@pytest.mark.parametrize("kernel", ["auto", "sparse", "dense"])
 @pytest.mark.parametrize("method", ["method1", "method2"])
 @pytest.mark.parametrize("n_perm", [0, 3, 100, 130, 700])
 def test_process_paths_matches_oracle(method, n_perm, kernel, monkeypatch):
@@ -61,7 +61,7 @@ def test_wide_masks_and_hypergeometric_table(method):
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
 
 
-@pytest.mark.parametrize("kernel", ["sparse", "dense"])
+@pytest.mark.parametrize("kernel", ["auto", "sparse", "dense"])
 @pytest.mark.parametrize("method,n_perm", [("method1", 1100), ("method2", 600), ("method1", 2500)])
 def test_baseline_mask_width_full_parity(method, n_perm, kernel, monkeypatch):
     """BASELINE configs[2] geometry (5,000 patients = 79 mask words, real -log hypergeometric table, K not a
