@@ -4,7 +4,8 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 package; the product (``geneticscre_amd``) never does.  It wraps ``oracle/gcre_oracle.cpp`` -- a CPU
 restatement of the reference's ``JoinExec`` (src/join_base.cpp, src/methods.h) -- through ctypes.
 
-Parity status: pinned by the SURVEY.md Appendix B known-answer vectors only (see gcre_oracle.h).
+Parity status: pinned by the SURVEY.md Appendix B known-answer vectors and by goldens generated from a partial
+build of the reference's own scoring headers (oracle/ref_partial -> tests/golden/ref_cases); see gcre_oracle.h.
 """
 from __future__ import annotations
 

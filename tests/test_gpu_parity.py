@@ -114,3 +114,37 @@ def test_dense_rows_through_the_sparse_kernel(method, monkeypatch):
     got, want = run_both(p)
     for lvl in range(1, 5):
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+
+
+from helpers import fnv_rows, load_ref_cases  # noqa: E402
+
+REF_CASES = load_ref_cases()
+
+
+@pytest.mark.parametrize("kernel", ["auto", "sparse", "dense"])
+@pytest.mark.parametrize("name,p,exp", REF_CASES, ids=[c[0] for c in REF_CASES])
+def test_hip_matches_reference_scoring_code(name, p, exp, kernel, monkeypatch):
+    """The HIP path against goldens printed by the reference's own scoring code (oracle/ref_partial): score values,
+    counts and f32 null maxima bit-exact at every level; ids wherever the score is not tied (the reference's choice
+    among ties is heap-order dependent)."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", kernel)
+    got = api.process_paths(p)
+    for lvl in range(1, p.path_length + 1):
+        e, r = exp[f"lst{lvl}"], got[f"lst{lvl}"]
+        assert [f"{int(b):016x}" for b in r.scores.view(np.uint64)] == e["scores"], (name, lvl)
+        assert [f"{int(b):08x}" for b in r.null.view(np.uint32)] == e["null"], (name, lvl)
+        assert sorted(zip(e["scores"], e["cases"], e["ctrls"])) == \
+               sorted(zip([f"{int(b):016x}" for b in r.scores.view(np.uint64)], r.cases.tolist(), r.ctrls.tolist()))
+        for k, s in enumerate(e["scores"]):
+            if e["scores"].count(s) == 1:
+                assert (r.src[k], r.trg[k]) == (e["src"][k], e["trg"][k]), (name, lvl, k)
+
+
+@pytest.mark.parametrize("name,p,exp", REF_CASES[:4], ids=[c[0] for c in REF_CASES[:4]])
+def test_hip_kept_rows_match_reference(name, p, exp):
+    """Rows written by the keep joins (levels 1a, 2, 3) hash to what the reference's PathSet held."""
+    plan = api.ResidentPlan(p)
+    plan.run()
+    for lvl, key in ((1, "lst1a"), (2, "lst2"), (3, "lst3")):
+        if lvl <= p.path_length:
+            assert fnv_rows(plan.kept[str(lvl)].to_numpy()) == exp[key]["kept_hash"], (name, key)

@@ -184,3 +184,26 @@ def test_harness_text_round_trip(tmp_path):
         np.testing.assert_array_equal(a[k].scores, b[k].scores)
         np.testing.assert_array_equal(a[k].null, b[k].null)
         np.testing.assert_array_equal(a[k].src, b[k].src)
+
+
+from helpers import fnv_rows, load_ref_cases  # noqa: E402
+
+REF_CASES = load_ref_cases()
+
+
+@pytest.mark.parametrize("name,p,exp", REF_CASES, ids=[c[0] for c in REF_CASES])
+def test_oracle_matches_reference_scoring_code(name, p, exp):
+    """Goldens printed by the reference's own score_permute / merge_scores / PathSet code (partial reference build,
+    oracle/ref_partial): every level's scores (bit patterns), ids in the reference's heap order, counts, f32 null
+    maxima and the kept path rows must match exactly."""
+    got = oracle.process_paths(p, order="reference", nthreads=0)
+    for lvl in range(1, p.path_length + 1):
+        e, r = exp[f"lst{lvl}"], got[f"lst{lvl}"]
+        assert [f"{int(b):016x}" for b in r.scores.view(np.uint64)] == e["scores"], (name, lvl)
+        assert r.src.tolist() == e["src"] and r.trg.tolist() == e["trg"], (name, lvl)
+        assert r.cases.tolist() == e["cases"] and r.ctrls.tolist() == e["ctrls"], (name, lvl)
+        assert [f"{int(b):08x}" for b in r.null.view(np.uint32)] == e["null"], (name, lvl)
+    for lvl, key in ((1, "lst1a"), (2, "lst2"), (3, "lst3")):
+        if lvl <= p.path_length:
+            assert fnv_rows(got[f"paths{lvl}"]) == exp[key]["kept_hash"], (name, key)
+            assert len(got[f"paths{lvl}"]) == exp[key]["kept_rows"]
