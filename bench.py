@@ -105,18 +105,77 @@ def cpu_baseline(prob, masks, budget_s=15.0):
     def run(n_uids):
         sub = UidRelSet(u.path_length, u.src[:n_uids], u.trg[:n_uids], u.count[:n_uids], u.location[:n_uids], u.signs)
         t0 = time.perf_counter()
-        ex.join(sub, p0[:n_uids], p1, keep=False)
-        return time.perf_counter() - t0, sub.count_total_paths()
+        res = ex.join(sub, p0[:n_uids], p1, keep=False)
+        return time.perf_counter() - t0, sub.count_total_paths(), res
 
     n_try = max(1, min(len(u), 64 * threads))
-    t, paths = run(n_try)
+    t, paths = run(n_try)[:2]
     rate = paths * prob.iterations / max(t, 1e-9)
     want_paths = rate * budget_s / max(prob.iterations, 1)
     n_uids = int(min(len(u), max(n_try, np.searchsorted(u.path_idx[1:], want_paths) + 1)))
-    t, paths = run(n_uids)
-    return {"value": paths * prob.iterations / t, "unit": "scores/s", "cores": threads, "kind": "port",
+    t, paths, port_res = run(n_uids)
+    port = {"value": paths * prob.iterations / t, "unit": "scores/s", "cores": threads, "kind": "port",
             "sample": f"level-{name} join, first {n_uids} uids = {paths} joined paths x {prob.iterations} permutations, "
                       f"{t:.1f} s wall, oracle/gcre_oracle.cpp -O3 -march=native"}
+    ref = reference_baseline(prob, masks, u, n_uids, p0, p1, threads, port_res)
+    if ref is None:
+        return port
+    ref["port"] = port
+    return ref
+
+
+def reference_baseline(prob, masks, u, n_uids, p0, p1, threads, port_res):
+    """The same sample through the reference's own scoring code: oracle/_ref/ref_driver links src/methods.h
+    (JoinMethod1/2::score_permute, >95 % of the reference's cycles, SURVEY §3.1) compiled from the reference tree;
+    the thread pool around it is the driver's (the reference's join_base.cpp needs Rcpp and cannot be built)."""
+    import struct
+    import subprocess
+    import tempfile
+    binary = None
+    for cand in ("ref_driver_v4", "ref_driver"):
+        path = os.path.join(ROOT, "oracle", "_ref", cand)
+        if os.path.exists(path):
+            try:
+                if subprocess.run([path, "--selftest"], capture_output=True, timeout=20).returncode == 0:
+                    binary = path
+                    break
+            except (OSError, subprocess.SubprocessError):
+                pass
+    if binary is None:
+        return None
+    M = 1 if prob.method == "method1" else 2
+    W = (prob.n_cases + prob.n_ctrls + 63) // 64
+    K = prob.iterations
+    table = np.ascontiguousarray(prob.value_table, dtype=np.float64)
+    rows0 = np.ascontiguousarray(p0[:n_uids], dtype=np.uint64)
+    rows1 = np.ascontiguousarray(p1, dtype=np.uint64)
+    with tempfile.NamedTemporaryFile(suffix=".gcrebin", delete=False) as f:
+        f.write(b"GCREBIN1")
+        f.write(struct.pack("<8i", M, prob.n_cases, prob.n_ctrls, K, W, prob.top_k, u.path_length, threads))
+        f.write(struct.pack("<5q", n_uids, rows1.shape[0], len(u.signs), table.shape[0], table.shape[1]))
+        f.write(np.ascontiguousarray(u.count[:n_uids], dtype=np.int32).tobytes())
+        f.write(np.ascontiguousarray(u.location[:n_uids], dtype=np.int64).tobytes())
+        f.write(np.ascontiguousarray(u.signs, dtype=np.int32).tobytes())
+        f.write(rows0.tobytes())
+        f.write(rows1.tobytes())
+        f.write(np.ascontiguousarray(masks[:K], dtype=np.uint64).tobytes())
+        f.write(table.tobytes())
+        tmp = f.name
+    try:
+        out = subprocess.run([binary, "--bench", tmp], capture_output=True, text=True, timeout=900)
+        if out.returncode != 0:
+            return None
+        res = json.loads(out.stdout)
+    except (OSError, subprocess.SubprocessError, ValueError):
+        return None
+    finally:
+        os.unlink(tmp)
+    same = [f"{int(b):08x}" for b in port_res.null.view(np.uint32)] == res["null"]
+    return {"value": res["paths"] * K / res["seconds"], "unit": "scores/s", "cores": threads, "kind": "reference",
+            "sample": f"level-{u.path_length} join, first {n_uids} uids = {res['paths']} joined paths x {K} permutations, "
+                      f"{res['seconds']:.1f} s wall; reference src/methods.h score_permute via {os.path.basename(binary)} "
+                      f"(partial reference build, -O3 AVX-512/AVX2; driver-side thread pool)",
+            "null_maxima_equal_port": same}
 
 
 def main():

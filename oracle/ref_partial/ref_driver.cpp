@@ -20,6 +20,7 @@
 #include "methods.h"
 #include "test.h"
 
+#include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <cstring>
@@ -85,19 +86,34 @@ joined_res JoinExec::join(const UidRelSet& uids, const PathSet& paths0, const Pa
   vector<float> global_null((size_t)iterations + 1, 0.0f), local_null((size_t)iterations + 1, 0.0f);
   perm_scores = global_null.data();
   const bool keep = paths_res.size != 0;
-  TJoinMethod m = createMethod(uids, local_null.data());
-  vector<uint64_t> row(paths_res.vlen ? paths_res.vlen : 1);
-  for (size_t idx = 0; idx < uids.size(); idx++) {
-    const uid_ref& u = uids[(int)idx];
-    st_path_count out = u.path_idx;
-    for (int j = 0; j < u.count; j++, out++) {
-      const st_pathset_size loc = u.location + j;
-      if (keep) fill(row.begin(), row.end(), 0);
-      m->score_permute((int)idx, (int)loc, paths0[(st_pathset_size)idx], paths1[loc], row.data(), keep);   // REFERENCE
-      if (keep) paths_res.set((st_pathset_size)out, row.data());
+  (void)local_null;
+  atomic<size_t> next(0);
+  mutex mu;
+  auto worker = [&]() {
+    vector<float> mine((size_t)iterations + 1, 0.0f);
+    TJoinMethod m = createMethod(uids, mine.data());
+    vector<uint64_t> row(paths_res.vlen ? paths_res.vlen : 1);
+    size_t idx;
+    while ((idx = next.fetch_add(1)) < uids.size()) {
+      const uid_ref& u = uids[(int)idx];
+      st_path_count out = u.path_idx;
+      for (int j = 0; j < u.count; j++, out++) {
+        const st_pathset_size loc = u.location + j;
+        if (keep) fill(row.begin(), row.end(), 0);
+        m->score_permute((int)idx, (int)loc, paths0[(st_pathset_size)idx], paths1[loc], row.data(), keep);   // REFERENCE
+        if (keep) paths_res.set((st_pathset_size)out, row.data());
+      }
     }
+    lock_guard<mutex> lock(mu);
+    m->merge_scores();                                                                                        // REFERENCE
+  };
+  if (nthreads <= 0) {
+    worker();
+  } else {
+    vector<thread> pool;
+    for (int t = 0; t < nthreads; t++) pool.emplace_back(worker);
+    for (auto& th : pool) th.join();
   }
-  m->merge_scores();                                                                                        // REFERENCE
   return format_result();
 }
 
@@ -137,7 +153,64 @@ static UidRelSet with_idx(int path_length, vector<uid_ref> uids, vector<int> sig
   return UidRelSet(path_length, uids, signs);
 }
 
+// ---- timing mode: one join on binary operands (written by bench.py), threads as given ------------------------------
+static bool read_exact(FILE* f, void* p, size_t n) { return n == 0 || fread(p, 1, n, f) == n; }
+
+static int bench_main(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", path); return 2; }
+  char magic[8];
+  int32_t h[8];
+  int64_t d[5];
+  if (!read_exact(f, magic, 8) || memcmp(magic, "GCREBIN1", 8) || !read_exact(f, h, sizeof h) || !read_exact(f, d, sizeof d)) return 2;
+  const int method = h[0], n_cases = h[1], n_ctrls = h[2], K = h[3], W = h[4], top_k = h[5], plen = h[6], nthreads = h[7];
+  const int64_t n_uids = d[0], n_rows1 = d[1], n_signs = d[2], t_rows = d[3], t_cols = d[4];
+  JoinExec exec(method == 1 ? "method1" : "method2", n_cases, n_ctrls, K);
+  exec.top_k = top_k;
+  exec.nthreads = nthreads;
+  if (exec.width_ul != W) { fprintf(stderr, "width mismatch\n"); return 2; }
+  vector<int32_t> cnt(n_uids), sg(n_signs);
+  vector<int64_t> loc(n_uids);
+  if (!read_exact(f, cnt.data(), cnt.size() * 4) || !read_exact(f, loc.data(), loc.size() * 8) || !read_exact(f, sg.data(), sg.size() * 4)) return 2;
+  vector<uid_ref> uv(n_uids);
+  for (int64_t i = 0; i < n_uids; i++) { uv[i].src = (int)i; uv[i].trg = 0; uv[i].count = cnt[i]; uv[i].location = (st_pathset_size)loc[i]; }
+  UidRelSet uids = with_idx(plen, uv, vector<int>(sg.begin(), sg.end()));
+  const int vlen = W * method;
+  auto p0 = exec.createPathSet((st_pathset_size)n_uids);
+  auto p1 = exec.createPathSet((st_pathset_size)n_rows1);
+  vector<uint64_t> row(vlen);
+  for (int64_t r = 0; r < n_uids; r++) { if (!read_exact(f, row.data(), (size_t)vlen * 8)) return 2; p0->set((st_pathset_size)r, row.data()); }
+  for (int64_t r = 0; r < n_rows1; r++) { if (!read_exact(f, row.data(), (size_t)vlen * 8)) return 2; p1->set((st_pathset_size)r, row.data()); }
+  vector<uint64_t> masks((size_t)K * W);
+  if (!read_exact(f, masks.data(), masks.size() * 8)) return 2;
+  {
+    // rebuild the K x n "label kept" rows setPermutedCases expects from the packed masks (bit = case under the permutation)
+    vec2d_i rows(K, vec_i(n_cases + n_ctrls));
+    for (int r = 0; r < K; r++)
+      for (int c = 0; c < n_cases + n_ctrls; c++) {
+        const int is_case = (int)((masks[(size_t)r * W + c / 64] >> (c % 64)) & 1);
+        rows[r][c] = (is_case == (c < n_cases ? 1 : 0)) ? 1 : 0;
+      }
+    if (K > 0) exec.setPermutedCases(rows);
+  }
+  vec2d_d table(t_rows, vec_d(t_cols));
+  for (auto& tr : table) if (!read_exact(f, tr.data(), (size_t)t_cols * 8)) return 2;
+  fclose(f);
+  exec.setValueTable(table);
+  auto none = exec.createPathSet(0);
+  const auto t0 = chrono::steady_clock::now();
+  joined_res res = exec.join(uids, *p0, *p1, *none);
+  const double secs = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
+  printf("{\"seconds\": %.6f, \"paths\": %llu, \"threads\": %d, \"best\": \"%016" PRIx64 "\", \"null\": [", secs,
+         (unsigned long long)uids.count_total_paths(), nthreads, res.scores.empty() ? 0 : bits(res.scores.back().score));
+  for (size_t k = 0; k < res.permuted_scores.size(); k++) printf("%s\"%08x\"", k ? ", " : "", bits((float)res.permuted_scores[k]));
+  printf("]}\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 2 && !strcmp(argv[1], "--selftest")) { printf("ok\n"); return 0; }
+  if (argc == 3 && !strcmp(argv[1], "--bench")) return bench_main(argv[2]);
   if (argc < 6) { fprintf(stderr, "usage: ref_driver <dump.txt> <method1|method2> <iterations> <top_k> <path_length>\n"); return 2; }
   ifstream f(argv[1]);
   const string method = argv[2];
