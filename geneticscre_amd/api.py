@@ -49,6 +49,21 @@ class gcre_level(ctypes.Structure):
                 ("signs", ctypes.c_void_p), ("n_signs", ctypes.c_int64)]
 
 
+class gcre_level_table(ctypes.Structure):
+    _fields_ = [("path_length", ctypes.c_int32), ("n_uids", ctypes.c_int64),
+                ("src", ctypes.POINTER(ctypes.c_int32)), ("trg", ctypes.POINTER(ctypes.c_int32)),
+                ("count", ctypes.POINTER(ctypes.c_int32)), ("location", ctypes.POINTER(ctypes.c_int64)),
+                ("n_signs", ctypes.c_int64), ("signs", ctypes.POINTER(ctypes.c_int32)), ("total_paths", ctypes.c_int64)]
+
+
+class gcre_levels(ctypes.Structure):
+    _fields_ = [("level", gcre_level_table * 6), ("n_data_inds", ctypes.c_int64 * 4),
+                ("data_inds", ctypes.POINTER(ctypes.c_int32) * 4), ("n_rels3", ctypes.c_int64),
+                ("r3_src", ctypes.POINTER(ctypes.c_int32)), ("r3_trg", ctypes.POINTER(ctypes.c_int32)),
+                ("r3_sign", ctypes.POINTER(ctypes.c_int32)), ("r3_trg2", ctypes.POINTER(ctypes.c_int32)),
+                ("r3_sign2", ctypes.POINTER(ctypes.c_int32))]
+
+
 class gcre_pp_input(ctypes.Structure):
     _fields_ = [("level", gcre_level * 6), ("data_inds", ctypes.c_void_p * 4), ("n_data_inds", ctypes.c_int64 * 4),
                 ("data1", ctypes.c_void_p), ("data1_rows", ctypes.c_int64),
@@ -66,7 +81,8 @@ EXPORTS = [
     "gcre_pathset_from_dense", "gcre_pathset_from_words", "gcre_pathset_select", "gcre_pathset_size",
     "gcre_pathset_read", "gcre_pathset_free", "gcre_join", "gcre_result_free", "gcre_uids_create",
     "gcre_uids_total_paths", "gcre_uids_free", "gcre_join_uids", "gcre_get_profile",
-    "gcre_process_paths", "gcre_resolve_count_locs",
+    "gcre_process_paths", "gcre_resolve_count_locs", "gcre_build_levels", "gcre_levels_free", "gcre_values_table",
+    "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask",
 ]
 
 
@@ -125,6 +141,14 @@ def load_library():
     lib.gcre_get_profile.argtypes = [V, ctypes.POINTER(gcre_profile)]
     lib.gcre_process_paths.argtypes = [V, ctypes.POINTER(gcre_pp_input), ctypes.POINTER(gcre_result)]
     lib.gcre_resolve_count_locs.argtypes = [P, I64, P, P, P, I64, P, P]
+    lib.gcre_build_levels.argtypes = [ctypes.c_int32, P, P, P, I64, ctypes.POINTER(gcre_levels)]
+    lib.gcre_levels_free.argtypes = [ctypes.POINTER(gcre_levels)]
+    lib.gcre_levels_free.restype = None
+    lib.gcre_values_table.argtypes = [I, I, P]
+    lib.gcre_generate_perm_masks.argtypes = [V, ctypes.c_uint64, P, I]
+    lib.gcre_mix64.restype = ctypes.c_uint64
+    lib.gcre_mix64.argtypes = [ctypes.c_uint64]
+    lib.gcre_get_perm_mask.argtypes = [V, I, P]
     _LIB = lib
     return lib
 
@@ -303,6 +327,19 @@ class JoinExec:
         m = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, self.width_ul)
         self._check(self._lib.gcre_set_perm_masks(self._h, _ptr(m), m.shape[0]))
 
+    def generate_permutations(self, seed: int, strata=None) -> None:
+        """Device-side getRandIndicesMat + getCaseORControl + setPermutedCases (R/Utils.R:22-46, 246-262)."""
+        if strata is None:
+            self._check(self._lib.gcre_generate_perm_masks(self._h, int(seed) & (2**64 - 1), None, 0))
+        else:
+            st = np.ascontiguousarray(strata, dtype=np.int32)
+            self._check(self._lib.gcre_generate_perm_masks(self._h, int(seed) & (2**64 - 1), _ptr(st), int(st.max()) + 1))
+
+    def perm_mask(self, r: int) -> np.ndarray:
+        out = np.zeros(self.width_ul, dtype=np.uint64)
+        self._check(self._lib.gcre_get_perm_mask(self._h, int(r), _ptr(out)))
+        return out
+
     def create_path_set(self, size: int) -> PathSet:
         return PathSet(self, self._lib.gcre_pathset_zeros(self._h, int(size)))
 
@@ -359,6 +396,49 @@ def resolve_count_locs(trg_uids, keys, counts, locations):
     if rc != GCRE_OK:
         raise GcreError(f"gcre_resolve_count_locs failed: {rc}")
     return oc, ol
+
+
+def build_levels(n_genes: int, src, trg, sign):
+    """Native build of the per-level join tables (R/ProcessPaths.R:206-256) -> geneticscre_amd.uids.LevelTables."""
+    from .uids import LevelTables, UidRelSet
+    lib = load_library()
+    s = np.ascontiguousarray(src, dtype=np.int32)
+    t = np.ascontiguousarray(trg, dtype=np.int32)
+    g = np.ascontiguousarray(sign, dtype=np.int32)
+    out = gcre_levels()
+    rc = lib.gcre_build_levels(int(n_genes), _ptr(s), _ptr(t), _ptr(g), len(s), ctypes.byref(out))
+    if rc == GCRE_ERR_RANGE:
+        raise IndexError("relation endpoint outside 0..n_genes-1")
+    if rc != GCRE_OK:
+        raise ValueError("relations must be sorted by (src, trg), unique, without self loops")
+
+    def arr(ptr, n, dt):
+        return np.ctypeslib.as_array(ptr, (n,)).astype(dt, copy=True) if n > 0 else np.zeros(0, dt)
+
+    names = ["1a", "1b", "2", "3", "4", "5"]
+    uids, n_paths = {}, {}
+    for i, name in enumerate(names):
+        lt = out.level[i]
+        uids[name] = UidRelSet(lt.path_length, arr(lt.src, lt.n_uids, np.int32), arr(lt.trg, lt.n_uids, np.int32),
+                               arr(lt.count, lt.n_uids, np.int32), arr(lt.location, lt.n_uids, np.int64),
+                               arr(lt.signs, lt.n_signs, np.int32))
+        n_paths[name] = int(lt.total_paths)
+    data_inds = {name: arr(out.data_inds[i], out.n_data_inds[i], np.int32) for i, name in enumerate(names[:4])}
+    n3 = out.n_rels3
+    rels3 = {"srcuid": arr(out.r3_src, n3, np.int32), "trguid": arr(out.r3_trg, n3, np.int32),
+             "sign": arr(out.r3_sign, n3, np.int32), "trguid2": arr(out.r3_trg2, n3, np.int32),
+             "sign2": arr(out.r3_sign2, n3, np.int32)}
+    lib.gcre_levels_free(ctypes.byref(out))
+    return LevelTables(uids, data_inds, rels3, n_paths)
+
+
+def values_table(n_cases: int, n_ctrls: int) -> np.ndarray:
+    """Native getValuesTable (R/Utils.R:137-159)."""
+    out = np.zeros((n_cases + 1, n_ctrls + 1), dtype=np.float64)
+    rc = load_library().gcre_values_table(int(n_cases), int(n_ctrls), _ptr(out))
+    if rc != GCRE_OK:
+        raise ValueError("bad table dimensions")
+    return out
 
 
 def process_paths(problem, device: int = 0, exec_: Optional[JoinExec] = None) -> Dict[str, object]:

@@ -1,0 +1,248 @@
+// gcre_frontend.hip -- native versions of the input builders that sit either side of the hot path in the
+// reference's R code (SURVEY.md §8f "next" rows):
+//   * gcre_build_levels          the per-level join tables GWASPA builds (R/ProcessPaths.R:206-256,
+//                                getUidsCountsLocations R/PathMethods.R:133-152, getRels3 src/wrapper.cpp:18-48)
+//   * gcre_values_table          getValuesTable, R/Utils.R:137-159
+//   * gcre_generate_perm_masks   getRandIndicesMat + getCaseORControl + setPermutedCases fused on the device
+//                                (R/Utils.R:22-46, 246-262; src/join_base.cpp:85-125)
+// None of this is on the scored path; it removes the K x n integer matrix (4 GB at BASELINE configs[3]) and the
+// O(n*m^2) R table builder from the caller's side.
+#include "../../include/gcre_hip.h"
+#include "gcre_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace gcre {
+
+// Permutation r keeps a uniformly random n_cases-subset of the patients as cases (what a uniform permutation of the
+// labels induces, Utils.R:22-46 + 246-262); with strata the number of cases inside every stratum is preserved
+// (Utils.R:8-13).  Selection sampling (Knuth, Algorithm S) per stratum: patient c becomes a case with probability
+// need/remaining.  Random numbers are a pure function of (seed, r, c) -- splitmix64 finaliser -- so the CPU
+// restatement in the tests reproduces every mask bit.
+__host__ __device__ inline uint64_t gcre_mix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+__global__ void k_generate_masks(uint64_t seed, int K, int n, int n_strata, const int32_t* stratum, const uint32_t* cases_in,
+                                 const uint32_t* size_of, uint32_t* work, int W32p, int Kpad, uint32_t* masks) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= K) return;
+  uint32_t* need = work + (size_t)r * n_strata * 2;
+  uint32_t* rem = need + n_strata;
+  for (int s = 0; s < n_strata; s++) { need[s] = cases_in[s]; rem[s] = size_of[s]; }
+  const uint64_t base = gcre_mix64(seed ^ (0x51ed270b7f3c9a1dull * (uint64_t)(r + 1)));
+  uint32_t word = 0;
+  for (int c = 0; c < n; c++) {
+    const int s = stratum ? stratum[c] : 0;
+    const uint64_t u = gcre_mix64(base + (uint64_t)c);
+    // u * rem >> 64 is uniform on [0, rem) up to 2^-64
+    const uint32_t pick = (uint32_t)(((unsigned __int128)u * rem[s]) >> 64);
+    if (pick < need[s]) {
+      word |= 1u << (c & 31);
+      need[s]--;
+    }
+    rem[s]--;
+    if ((c & 31) == 31 || c == n - 1) {
+      masks[(size_t)(c >> 5) * Kpad + r] = word;
+      word = 0;
+    }
+  }
+  for (int k = (n + 31) >> 5; k < W32p; k++) masks[(size_t)k * Kpad + r] = 0;
+}
+
+hipError_t launch_generate_masks(uint64_t seed, int K, int n, int n_strata, const int32_t* stratum, const uint32_t* cases_in,
+                                 const uint32_t* size_of, uint32_t* work, int W32p, int Kpad, uint32_t* masks,
+                                 hipStream_t stream) {
+  if (K == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_generate_masks, dim3((K + 63) / 64), dim3(64), 0, stream, seed, K, n, n_strata, stratum, cases_in,
+                     size_of, work, W32p, Kpad, masks);
+  return hipGetLastError();
+}
+
+}  // namespace gcre
+
+namespace {
+
+template <typename T>
+T* dup(const std::vector<T>& v) {
+  T* p = (T*)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (p && !v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+  return p;
+}
+
+void fill_level(gcre_level_table* lt, int plen, const std::vector<int32_t>& src, const std::vector<int32_t>& trg,
+                const std::vector<int32_t>& count, const std::vector<int64_t>& location, const std::vector<int32_t>& signs) {
+  lt->path_length = plen;
+  lt->n_uids = (int64_t)trg.size();
+  lt->src = dup(src);
+  lt->trg = dup(trg);
+  lt->count = dup(count);
+  lt->location = dup(location);
+  lt->n_signs = (int64_t)signs.size();
+  lt->signs = dup(signs);
+  int64_t t = 0;
+  for (int32_t c : count) t += std::max(c, 0);
+  lt->total_paths = t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcre_build_levels(int32_t n_genes, const int32_t* src, const int32_t* trg, const int32_t* sign, int64_t n_edges,
+                      gcre_levels* out) {
+  if (!out || n_genes < 0 || n_edges < 0 || (n_edges > 0 && (!src || !trg || !sign))) return GCRE_ERR_ARG;
+  std::memset(out, 0, sizeof *out);
+  // relations must arrive sorted by (src, trg), unique, without self loops (ProcessPaths.R:145-149, 210)
+  for (int64_t e = 0; e < n_edges; e++) {
+    if (src[e] < 0 || src[e] >= n_genes || trg[e] < 0 || trg[e] >= n_genes) return GCRE_ERR_RANGE;
+    if (e > 0 && (src[e] < src[e - 1] || (src[e] == src[e - 1] && trg[e] <= trg[e - 1]))) return GCRE_ERR_ARG;
+  }
+  // run-length index of the sorted source column: first edge and out-degree per gene (getUidsCountsLocations)
+  std::vector<int64_t> first((size_t)n_genes, -1);
+  std::vector<int32_t> deg((size_t)n_genes, 0);
+  for (int64_t e = 0; e < n_edges; e++) {
+    if (deg[(size_t)src[e]]++ == 0) first[(size_t)src[e]] = e;
+  }
+  std::vector<int32_t> genes((size_t)n_genes), ones((size_t)n_genes, 1);
+  std::vector<int64_t> self((size_t)n_genes);
+  for (int32_t g = 0; g < n_genes; g++) { genes[(size_t)g] = g; self[(size_t)g] = g; }
+  // level 1a: every gene joined with its own data row (ProcessPaths.R:214-218)
+  fill_level(&out->level[0], 1, genes, genes, ones, self, ones);
+  out->data_inds[0] = dup(genes);
+  out->n_data_inds[0] = n_genes;
+  // level 1b: genes that are the source of a relation (Ents2, ProcessPaths.R:153-155, 220-224)
+  std::vector<int32_t> genes2;
+  for (int32_t g = 0; g < n_genes; g++) if (deg[(size_t)g] > 0) genes2.push_back(g);
+  {
+    std::vector<int32_t> one2(genes2.size(), 1), idx2(genes2.size());
+    std::vector<int64_t> loc2(genes2.size());
+    for (size_t i = 0; i < genes2.size(); i++) { idx2[i] = (int32_t)i; loc2[i] = (int64_t)i; }
+    fill_level(&out->level[1], 1, genes2, genes2, one2, loc2, one2);
+    out->data_inds[1] = dup(idx2);
+    out->n_data_inds[1] = (int64_t)idx2.size();
+  }
+  std::vector<int32_t> esrc(src, src + n_edges), etrg(trg, trg + n_edges), esign(sign, sign + n_edges);
+  // level 2: gene g joined with the data of each of its targets (ProcessPaths.R:226-230); no relations -> (0, -1)
+  {
+    std::vector<int32_t> cnt((size_t)n_genes);
+    std::vector<int64_t> loc((size_t)n_genes);
+    for (int32_t g = 0; g < n_genes; g++) { cnt[(size_t)g] = deg[(size_t)g]; loc[(size_t)g] = first[(size_t)g]; }
+    fill_level(&out->level[2], 2, genes, genes, cnt, loc, esign);
+    out->data_inds[2] = dup(etrg);
+    out->n_data_inds[2] = n_edges;
+  }
+  // level 3: edge a->b joined with the data of each target of b (ProcessPaths.R:232-236)
+  std::vector<int32_t> c3((size_t)n_edges);
+  std::vector<int64_t> l3((size_t)n_edges);
+  int64_t p3 = 0;
+  for (int64_t e = 0; e < n_edges; e++) {
+    c3[(size_t)e] = deg[(size_t)trg[e]];
+    l3[(size_t)e] = first[(size_t)trg[e]];
+    p3 += c3[(size_t)e];
+  }
+  fill_level(&out->level[3], 3, esrc, etrg, c3, l3, esign);
+  out->data_inds[3] = dup(etrg);
+  out->n_data_inds[3] = n_edges;
+  // Rels3 (getRels3, wrapper.cpp:18-48): one row per 2-edge walk a->b->c, grouped by the first edge
+  std::vector<int32_t> r_src((size_t)p3), r_trg((size_t)p3), r_sign((size_t)p3), r_trg2((size_t)p3), r_sign2((size_t)p3),
+      third((size_t)p3);
+  {
+    int64_t o = 0;
+    for (int64_t e = 0; e < n_edges; e++)
+      for (int64_t j = l3[(size_t)e]; j < l3[(size_t)e] + c3[(size_t)e]; j++, o++) {
+        r_src[(size_t)o] = src[e];
+        r_trg[(size_t)o] = trg[e];
+        r_sign[(size_t)o] = sign[e];
+        r_trg2[(size_t)o] = trg[j];
+        r_sign2[(size_t)o] = sign[j];
+        // sign of the third gene relative to a (+) first gene (ProcessPaths.R:243-245)
+        third[(size_t)o] = (sign[e] * sign[j] == -1) ? -1 : 1;
+      }
+  }
+  out->n_rels3 = p3;
+  out->r3_src = dup(r_src);
+  out->r3_trg = dup(r_trg);
+  out->r3_sign = dup(r_sign);
+  out->r3_trg2 = dup(r_trg2);
+  out->r3_sign2 = dup(r_sign2);
+  // level 4: 3-path a->b->c joined with the stored 2-paths c->d (ProcessPaths.R:247-250)
+  {
+    std::vector<int32_t> cnt((size_t)p3);
+    std::vector<int64_t> loc((size_t)p3);
+    for (int64_t i = 0; i < p3; i++) { cnt[(size_t)i] = deg[(size_t)r_trg2[(size_t)i]]; loc[(size_t)i] = first[(size_t)r_trg2[(size_t)i]]; }
+    fill_level(&out->level[4], 4, r_src, r_trg2, cnt, loc, third);
+  }
+  // level 5: 3-path a->b->c joined with the stored 3-paths c->d->e: Rels3 rows whose first gene is c, contiguous
+  // because Rels3 inherits the (src, trg) order (ProcessPaths.R:253-256)
+  {
+    std::vector<int64_t> first3((size_t)n_genes, -1);
+    std::vector<int32_t> deg3((size_t)n_genes, 0);
+    for (int64_t i = 0; i < p3; i++)
+      if (deg3[(size_t)r_src[(size_t)i]]++ == 0) first3[(size_t)r_src[(size_t)i]] = i;
+    std::vector<int32_t> cnt((size_t)p3);
+    std::vector<int64_t> loc((size_t)p3);
+    for (int64_t i = 0; i < p3; i++) { cnt[(size_t)i] = deg3[(size_t)r_trg2[(size_t)i]]; loc[(size_t)i] = first3[(size_t)r_trg2[(size_t)i]]; }
+    fill_level(&out->level[5], 5, r_src, r_trg2, cnt, loc, third);
+  }
+  return GCRE_OK;
+}
+
+void gcre_levels_free(gcre_levels* lv) {
+  if (!lv) return;
+  for (auto& l : lv->level) {
+    std::free(l.src); std::free(l.trg); std::free(l.count); std::free(l.location); std::free(l.signs);
+  }
+  for (auto* p : lv->data_inds) std::free(p);
+  std::free(lv->r3_src); std::free(lv->r3_trg); std::free(lv->r3_sign); std::free(lv->r3_trg2); std::free(lv->r3_sign2);
+  std::memset(lv, 0, sizeof *lv);
+}
+
+int gcre_values_table(int n_cases, int n_ctrls, double* out) {
+  // getValuesTable (Utils.R:137-159): out[x][i-x] = -log(two-sided hypergeometric p of x cases among i carriers);
+  // two-sided p = mass of all outcomes no more likely than x (:153); infinities -> max finite + 1 (:156).
+  // Outcomes that tie in exact arithmetic (C(5,2)C(9,5) == C(5,3)C(9,4)) differ by an ulp or two after lgamma/exp;
+  // R's exact `<=` leaves such ties to dhyper's rounding, here they count as ties (relative slack 1e-12).
+  if (n_cases < 0 || n_ctrls < 0 || !out) return GCRE_ERR_ARG;
+  const int n = n_cases + n_ctrls;
+  const size_t cols = (size_t)n_ctrls + 1;
+  auto lchoose = [](double a, double b) { return std::lgamma(a + 1.0) - std::lgamma(b + 1.0) - std::lgamma(a - b + 1.0); };
+  std::vector<double> prob, sorted, csum;
+  double max_finite = -std::numeric_limits<double>::infinity();
+  for (int i = 0; i <= n; i++) {
+    const int lo = std::max(0, i - n_ctrls), hi = std::min(i, n_cases);
+    const size_t m = (size_t)(hi - lo + 1);
+    prob.resize(m);
+    const double denom = lchoose(n, i);
+    for (size_t k = 0; k < m; k++) {
+      const int x = lo + (int)k;
+      prob[k] = std::exp(lchoose(n_cases, x) + lchoose(n_ctrls, i - x) - denom);   // dhyper(x, nCases, nControls, i)
+    }
+    sorted = prob;
+    std::stable_sort(sorted.begin(), sorted.end());
+    csum.resize(m);
+    double run = 0;
+    for (size_t k = 0; k < m; k++) { run += sorted[k]; csum[k] = run; }
+    for (size_t k = 0; k < m; k++) {
+      const size_t upto = (size_t)(std::upper_bound(sorted.begin(), sorted.end(), prob[k] * (1.0 + 1e-12)) - sorted.begin());
+      const double v = -std::log(csum[upto - 1]);
+      out[(size_t)(lo + (int)k) * cols + (size_t)(i - lo - (int)k)] = v;
+      if (std::isfinite(v)) max_finite = std::max(max_finite, v);
+    }
+  }
+  for (size_t k = 0; k < ((size_t)n_cases + 1) * cols; k++)
+    if (!std::isfinite(out[k])) out[k] = max_finite + 1.0;
+  return GCRE_OK;
+}
+
+uint64_t gcre_mix64(uint64_t z) { return gcre::gcre_mix64(z); }
+
+}  // extern "C"

@@ -928,6 +928,52 @@ int gcre_set_perm_masks(gcre_ctx* c, const uint64_t* masks, int nrow) {
   return GCRE_OK;
 }
 
+int gcre_generate_perm_masks(gcre_ctx* c, uint64_t seed, const int32_t* stratum, int n_strata) {
+  if (!c || (stratum && n_strata < 1)) return fail(c, GCRE_ERR_ARG, "bad strata");
+  (void)hipSetDevice(c->device);
+  const Geometry& g = c->g;
+  if (g.K == 0) { c->have_perms = true; return GCRE_OK; }
+  if (!stratum) n_strata = 1;
+  // cases are the first n_cases patient columns (join_base.cpp:50-54): cases and size per stratum
+  std::vector<uint32_t> cases_in((size_t)n_strata, 0), size_of((size_t)n_strata, 0);
+  for (int q = 0; q < g.n; q++) {
+    const int s = stratum ? stratum[q] : 0;
+    if (s < 0 || s >= n_strata) return fail(c, GCRE_ERR_RANGE, "stratum id out of range");
+    size_of[(size_t)s]++;
+    if (q < g.n_cases) cases_in[(size_t)s]++;
+  }
+  uint32_t *d_cases = nullptr, *d_size = nullptr, *d_work = nullptr;
+  int32_t* d_str = nullptr;
+  hipError_t e = hipMalloc((void**)&d_cases, (size_t)n_strata * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_size, (size_t)n_strata * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_work, (size_t)g.K * n_strata * 2 * 4);
+  if (e == hipSuccess && stratum) e = hipMalloc((void**)&d_str, (size_t)g.n * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_cases, cases_in.data(), (size_t)n_strata * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_size, size_of.data(), (size_t)n_strata * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && stratum) e = hipMemcpyAsync(d_str, stratum, (size_t)g.n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess)
+    e = launch_generate_masks(seed, g.K, g.n, n_strata, d_str, d_cases, d_size, d_work, 2 * g.Wp, g.Kpad, c->d_masks, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  for (void* p : {(void*)d_cases, (void*)d_size, (void*)d_work, (void*)d_str})
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("generate_perm_masks: ") + hipGetErrorString(e));
+  if (int rc = build_transposed_masks(c)) return rc;
+  c->have_perms = true;
+  return GCRE_OK;
+}
+
+int gcre_get_perm_mask(gcre_ctx* c, int r, uint64_t* out) {
+  if (!c || !out) return GCRE_ERR_ARG;
+  const Geometry& g = c->g;
+  if (r < 0 || r >= g.K) return fail(c, GCRE_ERR_RANGE, "permutation index out of range");
+  (void)hipSetDevice(c->device);
+  std::vector<uint32_t> col((size_t)2 * g.Wp);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy2D(col.data(), 4, c->d_masks + r, (size_t)g.Kpad * 4, 4, (size_t)2 * g.Wp, hipMemcpyDeviceToHost));
+  for (int k = 0; k < g.W; k++) out[k] = (uint64_t)col[(size_t)2 * k] | ((uint64_t)col[(size_t)2 * k + 1] << 32);
+  return GCRE_OK;
+}
+
 // ---- path sets ----
 gcre_pathset* gcre_pathset_zeros(gcre_ctx* c, int64_t nrows) {
   if (!c) return nullptr;
@@ -1144,7 +1190,10 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
 
   int rc = gcre_set_value_table(c, in->value_table, in->vt_rows, in->vt_cols, in->vt_col_major);   // wrapper.cpp:213
   if (rc != GCRE_OK) return rc;
-  rc = gcre_set_perm_cases(c, in->perm_cases, in->perm_rows, c->g.n, in->perm_col_major);          // wrapper.cpp:214
+  // a context whose masks were generated on the device (gcre_generate_perm_masks) or uploaded packed keeps them
+  // when the caller passes no matrix; otherwise wrapper.cpp:214
+  if (!(in->perm_cases == nullptr && in->perm_rows == 0 && c->have_perms))
+    rc = gcre_set_perm_cases(c, in->perm_cases, in->perm_rows, c->g.n, in->perm_col_major);
   if (rc != GCRE_OK) return rc;
 
   gcre_pathset *parsed1 = nullptr, *parsed2 = nullptr, *paths1 = nullptr, *paths2 = nullptr, *paths3 = nullptr;

@@ -40,8 +40,9 @@ def values_table(n_cases: int, n_ctrls: int) -> np.ndarray:
         prob = np.exp(lchoose(n_cases, x) + lchoose(n_ctrls, i - x) - lchoose(n, i))   # dhyper(x, nCases, nControls, i)
         order = np.argsort(prob, kind="stable")
         csum = np.cumsum(prob[order])
-        # two-sided p: mass of all outcomes no more likely than x (Utils.R:153)
-        p_two = csum[np.searchsorted(prob[order], prob, side="right") - 1]
+        # two-sided p: mass of all outcomes no more likely than x (Utils.R:153); outcomes that tie in exact
+        # arithmetic count as ties whatever the last ulp of gammaln says (same slack as gcre_values_table)
+        p_two = csum[np.searchsorted(prob[order], prob * (1.0 + 1e-12), side="right") - 1]
         with np.errstate(divide="ignore"):
             table[x, i - x] = -np.log(p_two)
     finite = np.isfinite(table)

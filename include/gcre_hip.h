@@ -153,7 +153,8 @@ typedef struct {
   int data_col_major;            /* R matrices are column-major */
   const double* value_table;
   int vt_rows, vt_cols, vt_col_major;
-  const int32_t* perm_cases;     /* iterations x patients, may be NULL with 0 rows */
+  const int32_t* perm_cases;     /* iterations x patients; NULL with 0 rows = keep the masks the context already
+                                  * holds (gcre_generate_perm_masks / gcre_set_perm_masks), an error if it has none */
   int perm_rows, perm_col_major;
   int path_length;               /* 1..5 */
 } gcre_pp_input;
@@ -166,6 +167,52 @@ int gcre_process_paths(gcre_ctx* ctx, const gcre_pp_input* in, gcre_result out[5
 int gcre_resolve_count_locs(const int32_t* trg_uids, int64_t n_uids,
                             const int32_t* keys, const int32_t* counts, const int32_t* locations, int64_t n_keys,
                             int32_t* out_count, int64_t* out_location);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Callers and data formats either side of the path: native versions of what GWASPA prepares in R.
+ * Not needed by the .Call drop-in (R keeps doing this work); used by non-R front ends and by the benchmark.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* One join level as GWASPA builds it (R/ProcessPaths.R:214-256): uid_ref rows + UidRelSet::signs. */
+typedef struct {
+  int32_t path_length;
+  int64_t n_uids;
+  int32_t* src;         /* uid_ref.src */
+  int32_t* trg;         /* uid_ref.trg */
+  int32_t* count;       /* uid_ref.count */
+  int64_t* location;    /* uid_ref.location (-1 where count == 0, R/PathMethods.R:147) */
+  int64_t n_signs;
+  int32_t* signs;
+  int64_t total_paths;  /* UidRelSet::count_total_paths */
+} gcre_level_table;
+
+typedef struct {
+  gcre_level_table level[6];   /* 1a, 1b, 2, 3, 4, 5 */
+  int64_t n_data_inds[4];
+  int32_t* data_inds[4];       /* 1a, 1b, 2, 3: 0-based rows of data1 / data2 */
+  int64_t n_rels3;             /* getRels3 (src/wrapper.cpp:18-48): one row per 2-edge walk */
+  int32_t *r3_src, *r3_trg, *r3_sign, *r3_trg2, *r3_sign2;
+} gcre_levels;
+
+/* Relations must be sorted by (src, trg), unique, without self loops; gene ids are 0..n_genes-1 = rows of the data
+ * matrix (what GWASPA's filtering leaves, R/ProcessPaths.R:133-167, 210).  Arrays are malloc'ed; free with
+ * gcre_levels_free. */
+int gcre_build_levels(int32_t n_genes, const int32_t* src, const int32_t* trg, const int32_t* sign, int64_t n_edges,
+                      gcre_levels* out);
+void gcre_levels_free(gcre_levels* levels);
+
+/* getValuesTable (R/Utils.R:137-159): out[(n_cases+1) x (n_ctrls+1)] row-major, -log two-sided hypergeometric p.
+ * Parity with R's stats::dhyper is unpinned (no R in the build image); the scorer treats the table as opaque input. */
+int gcre_values_table(int n_cases, int n_ctrls, double* out);
+
+/* getRandIndicesMat + getCaseORControl + setPermutedCases (R/Utils.R:22-46, 246-262; src/join_base.cpp:85-125) fused
+ * on the device: permutation r = a uniformly random relabelling that keeps n_cases cases (inside every stratum when
+ * `stratum[n]` is given, values 0..n_strata-1, R/Utils.R:8-13).  Deterministic in (seed, r, patient): see
+ * gcre_mix64 and k_generate_masks.  Replaces gcre_set_perm_cases for callers that do not need R's RNG stream. */
+int gcre_generate_perm_masks(gcre_ctx* ctx, uint64_t seed, const int32_t* stratum, int n_strata);
+uint64_t gcre_mix64(uint64_t z);
+/* read permutation mask r back as width_ul words (bit c = patient c is a case under permutation r) */
+int gcre_get_perm_mask(gcre_ctx* ctx, int r, uint64_t* out);
 
 #ifdef __cplusplus
 }

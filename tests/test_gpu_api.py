@@ -179,3 +179,139 @@ def test_bench_two_ranks_reproduce_one_rank(tmp_path):
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2
     assert a["result_sha256"] == b["result_sha256"]
     assert a["config"]["scores_per_step"] == b["config"]["scores_per_step"]
+
+
+def _mix64(z):
+    M = (1 << 64) - 1
+    z = (z + 0x9E3779B97F4A7C15) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    return z ^ (z >> 31)
+
+
+def _masks_restated(seed, K, n, n_cases, strata):
+    """CPU restatement of k_generate_masks: selection sampling per stratum on splitmix64(seed, r, patient)."""
+    M = (1 << 64) - 1
+    strata = np.zeros(n, np.int64) if strata is None else np.asarray(strata)
+    S = int(strata.max()) + 1
+    out = []
+    for r in range(K):
+        need = [int(((strata == s) & (np.arange(n) < n_cases)).sum()) for s in range(S)]
+        rem = [int((strata == s).sum()) for s in range(S)]
+        base = _mix64(seed ^ ((0x51ED270B7F3C9A1D * (r + 1)) & M))
+        bits = 0
+        for c in range(n):
+            s = int(strata[c])
+            u = _mix64((base + c) & M)
+            if ((u * rem[s]) >> 64) < need[s]:
+                bits |= 1 << c
+                need[s] -= 1
+            rem[s] -= 1
+        out.append(bits)
+    return out
+
+
+@pytest.mark.parametrize("stratified", [False, True])
+def test_device_permutation_masks(stratified):
+    """gcre_generate_perm_masks: every mask is reproduced bit for bit by the CPU restatement, keeps exactly nCases
+    cases (inside every stratum when stratified, R/Utils.R:8-13), and feeds the scorer like uploaded masks do."""
+    nc, nt, K = 41, 59, 37
+    n = nc + nt
+    strata = (np.arange(n) * 7 % 3).astype(np.int32) if stratified else None
+    p = make_problem(25, 60, nc, nt, K, 3, method="method1", top_k=5, seed=91, table=small_table(nc, nt))
+    ex = api.JoinExec("method1", nc, nt, K)
+    ex.generate_permutations(1234567, strata)
+    want = _masks_restated(1234567, K, n, nc, strata)
+    got = []
+    for r in range(K):
+        words = ex.perm_mask(r)
+        got.append(sum(int(w) << (64 * k) for k, w in enumerate(words)))
+    assert got == want
+    for bits in got:
+        assert bin(bits).count("1") == nc
+        if stratified:
+            for s in range(3):
+                sel = [c for c in range(n) if strata[c] == s]
+                assert sum((bits >> c) & 1 for c in sel) == sum(1 for c in sel if c < nc)
+    assert len(set(got)) > K // 2                                   # they are not all the same permutation
+    # scoring with generated masks == scoring with the same masks uploaded packed
+    packed = np.array([[(b >> (64 * k)) & (2**64 - 1) for k in range((n + 63) // 64)] for b in got], dtype=np.uint64)
+    ex.top_k = 5
+    ex.set_value_table(p.value_table)
+    ex2 = api.JoinExec("method1", nc, nt, K)
+    ex2.top_k = 5
+    ex2.set_value_table(p.value_table)
+    ex2.set_permuted_masks(packed)
+    u = p.levels.uids["2"]
+    d1, d2 = ex.load(p.data1), ex2.load(p.data1)
+    a = ex.join(u, d1, d1.select(p.levels.data_inds["2"]))
+    b = ex2.join(u, d2, d2.select(p.levels.data_inds["2"]))
+    np.testing.assert_array_equal(a.null.view(np.uint32), b.null.view(np.uint32))
+
+
+def _gwaspa_case(seed, n_genes=60, n_edges=200, nc=48, nt=52):
+    """A dataset + knowledge base with extra genes on either side and one planted 3-gene pathway whose union of
+    carriers is (almost) all cases."""
+    rng = np.random.default_rng(seed)
+    g, src, trg, sign = synth.signed_network(n_genes, n_edges, rng)
+    uid = np.arange(g) * 5 + 100
+    symbols = [f"G{u}" for u in uid]
+    n = nc + nt
+    data = (rng.random((g, n)) < 0.02).astype(np.int32)
+    # plant: walk a -> b -> c; each gene carries a disjoint third of the first 15 cases (each stays under the threshold)
+    a = int(src[0]); b = int(trg[0])
+    nxt = np.flatnonzero(src == b)
+    c = int(trg[nxt[0]])
+    for k, gene in enumerate((a, b, c)):
+        data[gene] = 0
+        data[gene, 5 * k:5 * k + 5] = 1
+    genes = symbols + ["ORPHAN"]                                    # a gene the knowledge base does not know
+    data = np.vstack([data, np.zeros((1, n), np.int32)])
+    ents_uid = np.concatenate([uid, [9999]])                        # an entity without data
+    ents_sym = symbols + ["NODATA"]
+    rs = np.concatenate([uid[src], [uid[0]]])
+    rt = np.concatenate([uid[trg], [9999]])                         # a relation that points outside the dataset
+    rg = np.concatenate([sign, [1]])
+    return genes, data, (ents_uid, ents_sym, rs, rt, rg), (f"G{uid[a]}", f"G{uid[b]}", f"G{uid[c]}")
+
+
+@pytest.mark.parametrize("signed", [False, True])
+def test_gwaspa_front_end_matches_oracle_and_finds_planted_pathway(signed):
+    """report.gwaspa: native table + native level tables + device permutations + device scoring + getPaths decoding.
+    Every level's lists equal the oracle's on the same masks (read back from the device); the planted pathway
+    is the best length-3 row with p == 0."""
+    from geneticscre_amd import report
+    nc, nt, K = 48, 52, 64
+    genes, data, network, planted = _gwaspa_case(5)
+    out = report.gwaspa(genes, data, nc, nt, network, signed=signed, threshold=0.2, top_k=8, path_length=4,
+                        n_permutations=K, seed=77)
+    df = out["GWASPA.Results"]
+    assert list(df.columns) == report.COLUMNS and len(df) == 8 * 4
+    assert (np.diff(df["Pvalues"].to_numpy()) >= 0).all()
+    best3 = df[df["Lengths"] == 3].iloc[0]
+    assert best3["Paths"] == " -> ".join(planted) and best3["Pvalues"] == 0.0
+    if not signed:                       # method2 splits carriers by the sign of the gene they sit on
+        assert best3["Cases"] == 15 and best3["Controls"] <= 3
+
+    # same masks through the oracle: label kept <=> (patient is a case) == (mask bit)
+    prep = out["prepared"]
+    ex = api.JoinExec("method2" if signed else "method1", nc, nt, K)
+    ex.generate_permutations(77)
+    bits = np.array([[(int(ex.perm_mask(r)[c // 64]) >> (c % 64)) & 1 for c in range(nc + nt)] for r in range(K)])
+    ex.close()
+    kept = (bits == (np.arange(nc + nt) < nc)[None, :]).astype(np.int32)
+    lv = api.build_levels(len(prep.ents_uid), prep.src, prep.trg, prep.sign)
+    n2 = len(prep.ents2_uid)
+    from geneticscre_amd.uids import UidRelSet
+    ids2 = np.arange(n2, dtype=np.int32)
+    lv.uids["1b"] = UidRelSet(1, ids2, ids2, np.ones(n2, np.int32), np.arange(n2, dtype=np.int64), np.ones(n2, np.int32))
+    lv.data_inds["1b"], lv.n_paths["1b"] = ids2, n2
+    p = synth.Problem("method2" if signed else "method1", nc, nt, 4, 8, K, lv, prep.data1, prep.data2,
+                      api.values_table(nc, nt), kept, 0)
+    want = oracle.process_paths(p, order="canonical")
+    for L in range(1, 5):
+        g, w = out["levels"][f"lst{L}"], want[f"lst{L}"]
+        np.testing.assert_array_equal(g.null.view(np.uint32), w.null.view(np.uint32), err_msg=f"null L{L}")
+        np.testing.assert_array_equal(g.scores.view(np.uint64), w.scores.view(np.uint64))
+        np.testing.assert_array_equal(g.cases, w.cases)
+        np.testing.assert_array_equal(g.ctrls, w.ctrls)

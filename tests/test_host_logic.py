@@ -175,3 +175,29 @@ def test_two_rank_exchange_over_gloo(method, tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_rank_main, args=(2, port, method, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "rank0.ok").read() == "1" and open(tmp_path / "rank1.ok").read() == "1"
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_native_level_tables_equal_python_restatement(seed):
+    """gcre_build_levels (C++) == uids.build_level_tables (numpy) == the R construction, on random signed networks."""
+    rng = np.random.default_rng(seed)
+    g, src, trg, sign = synth.signed_network(60 + 40 * seed, 200 + 150 * seed, rng)
+    a = build_level_tables(g, src, trg, sign)
+    b = api.build_levels(g, src, trg, sign)
+    for k in ("1a", "1b", "2", "3", "4", "5"):
+        for f in ("src", "trg", "count", "location", "signs"):
+            np.testing.assert_array_equal(getattr(a.uids[k], f), getattr(b.uids[k], f), err_msg=f"{k}.{f}")
+        assert a.n_paths[k] == b.n_paths[k]
+    for k in ("1a", "1b", "2", "3"):
+        np.testing.assert_array_equal(a.data_inds[k], b.data_inds[k])
+    for k in a.rels3:
+        np.testing.assert_array_equal(a.rels3[k], b.rels3[k])
+    with pytest.raises(ValueError):
+        api.build_levels(g, src[::-1].copy(), trg[::-1].copy(), sign)          # not sorted
+
+
+def test_native_values_table_matches_numpy_restatement():
+    for nc, nt in ((12, 12), (5, 9), (40, 33), (250, 250)):
+        a, b = synth.values_table(nc, nt), api.values_table(nc, nt)
+        assert a.shape == b.shape and np.isfinite(b).all()
+        np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-9)
