@@ -41,7 +41,9 @@ class gcre_profile(ctypes.Structure):
     _fields_ = [("null_kernel_ms", ctypes.c_double), ("null_kernel_launches", ctypes.c_int64),
                 ("stats_kernel_ms", ctypes.c_double), ("select_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
                 ("paths", ctypes.c_int64), ("scores", ctypes.c_int64), ("null_alg_bytes", ctypes.c_double),
-                ("null_row_loads", ctypes.c_double)]
+                ("null_row_loads", ctypes.c_double), ("ie_launches", ctypes.c_int64),
+                ("ie_overlap_lists", ctypes.c_int64), ("ie_hinted_joins", ctypes.c_int64),
+                ("ie_plane_joins", ctypes.c_int64)]
 
 
 class gcre_level(ctypes.Structure):
@@ -82,7 +84,7 @@ EXPORTS = [
     "gcre_pathset_read", "gcre_pathset_free", "gcre_join", "gcre_result_free", "gcre_uids_create",
     "gcre_uids_total_paths", "gcre_uids_free", "gcre_join_uids", "gcre_get_profile",
     "gcre_process_paths", "gcre_resolve_count_locs", "gcre_build_levels", "gcre_levels_free", "gcre_values_table",
-    "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask",
+    "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask", "gcre_uids_set_reduced",
 ]
 
 
@@ -149,6 +151,7 @@ def load_library():
     lib.gcre_mix64.restype = ctypes.c_uint64
     lib.gcre_mix64.argtypes = [ctypes.c_uint64]
     lib.gcre_get_perm_mask.argtypes = [V, I, P]
+    lib.gcre_uids_set_reduced.argtypes = [V, V, P, I64]
     _LIB = lib
     return lib
 
@@ -247,6 +250,17 @@ class DeviceUids:
         if not self._h:
             owner._raise()
         self.total_paths = int(owner._lib.gcre_uids_total_paths(self._h))
+        self._reduced = None
+
+    def set_reduced(self, reduced: Optional["PathSet"], index=None) -> None:
+        """gcre_uids_set_reduced: paths0[idx] | paths1[loc] == paths0[idx] | reduced[index[loc]] (checked per join)."""
+        if reduced is None:
+            self._owner._check(self._owner._lib.gcre_uids_set_reduced(self._h, None, None, 0))
+            self._reduced = None
+            return
+        idx = np.ascontiguousarray(np.asarray(index).astype(np.int64) & 0xFFFFFFFF, dtype=np.uint32)   # bit 31 = swap halves
+        self._owner._check(self._owner._lib.gcre_uids_set_reduced(self._h, reduced._h, _ptr(idx), len(idx)))
+        self._reduced = reduced     # keeps the operand alive
 
     def free(self) -> None:
         h, self._h = self._h, None
@@ -515,13 +529,29 @@ class ResidentPlan:
             self.inputs["2"] = parsed1.select(lv.data_inds["3"])   # wrapper.cpp:207 reads data_idx2 from r_data_inds3
         if L >= 3:
             self.inputs["3"] = parsed1.select(lv.data_inds["3"])
-        parsed1.free()
-        parsed2.free()
+        self.parsed = (parsed1, parsed2)
         self.kept = {"1": ex.create_path_set(self.uids["1a"].total_paths)}
         if L >= 2:
             self.kept["2"] = ex.create_path_set(self.uids["2"].total_paths)
         if L >= 3:
             self.kept["3"] = ex.create_path_set(self.uids["3"].total_paths)
+        # what every join really adds to paths0 (gcre_uids_set_reduced; the same hints gcre_process_paths attaches)
+        self.uids["1a"].set_reduced(parsed1, lv.data_inds["1a"])
+        self.uids["1b"].set_reduced(parsed2, lv.data_inds["1b"])
+        signed = problem.method == "method2"
+        rel_neg = (np.asarray(lv.uids["2"].signs) != 1) if signed else np.zeros(len(lv.uids["2"].signs), bool)
+        for name in ("2", "3"):
+            if name in self.uids:
+                self.uids[name].set_reduced(parsed1, lv.data_inds["3"])
+        if "4" in self.uids:    # level 2 put the added gene into the (-) half of paths2[loc] when the relation is negative
+            self.uids["4"].set_reduced(parsed1, np.asarray(lv.data_inds["3"], np.int64) | (rel_neg.astype(np.int64) << 31))
+        if "5" in self.uids:    # paths3[loc] = (c, d, e): the join adds paths2[(d, e)], swapped when (c, d) is negative
+            u3 = lv.uids["3"]
+            cnt = np.maximum(np.asarray(u3.count, dtype=np.int64), 0)
+            start = np.repeat(np.asarray(u3.location, dtype=np.int64), cnt)
+            within = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            first_neg = np.repeat((np.asarray(u3.signs)[:len(cnt)] != 1) if signed else np.zeros(len(cnt), bool), cnt)
+            self.uids["5"].set_reduced(self.kept["2"], (start + within) | (first_neg.astype(np.int64) << 31))
 
     def operands(self, name: str):
         """(paths0, paths1, paths_res) of one level, as in wrapper.cpp:227-276."""

@@ -81,14 +81,17 @@ struct gcre_ctx {
   double* d_dmax = nullptr;          // method 2 null table (vtmax)
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
-  uint32_t* d_max_tot = nullptr;     // 1 word: largest carrier total of the current chunk
-  int null_kernel = 0;               // 0 auto, 1 dense, 2 sparse (GCRE_NULL_KERNEL)
+  uint32_t* d_max_tot = nullptr;     // 2 words: largest carrier total of the current chunk, "reduced operand is wrong" flag
+  uint32_t* d_ladder = nullptr;      // method 1: pruning ladder of the null table [kLadderLevels][TD]
+  int null_kernel = 0;               // 0 auto, 1 dense, 2 sparse, 3 ie (GCRE_NULL_KERNEL)
   int sparse_waves_per_cu = 32;
+  int ie_prune = 1;                  // GCRE_IE_PRUNE=0 looks every count up (diagnostics)
+  uint64_t mask_epoch = 0;           // bumped whenever the permutation masks change: count planes are per epoch
 
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
   DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan;
-  DevBuf<uint32_t> d_dcnt, d_dlist;
+  DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
 
   gcre_profile prof{};
@@ -104,6 +107,13 @@ struct gcre_pathset {
   mutable uint64_t* d_loff = nullptr;
   mutable uint32_t* d_lidx = nullptr;
   mutable std::vector<uint64_t> h_loff;   // host copy of the offsets (sizes the work of a sparse launch)
+  mutable uint32_t max_bits = 0;          // longest list (entries incl. padding): bounds the carriers of any row
+  mutable bool max_known = false;
+  // count planes for the inclusion-exclusion kernel: [row*M+h][nkt][groups][64][4] dwords, valid for one mask epoch
+  mutable uint32_t* d_planes = nullptr;
+  mutable int plane_groups = 0;
+  mutable uint64_t planes_epoch = 0;
+  mutable bool planes_valid = false;
 };
 
 // UidRelSet (src/gcre.h:49-90) resident on the device: prefix sums of count, locations, signs
@@ -121,6 +131,11 @@ struct gcre_uids {
   std::vector<int64_t> h_path_idx;   // host copy, for building the sparse kernel's segment tables
   struct SegCache { int64_t first, count; int64_t nsegs; SparseSeg* d_segs; };
   mutable std::vector<SegCache> seg_cache;
+  // optional hint (gcre_uids_set_reduced): paths0[idx] | paths1[loc] == paths0[idx] | red[red_index[loc]] for every
+  // joined path; checked on the device for every join, ignored when it does not hold
+  const gcre_pathset* red = nullptr;
+  int32_t* d_red_index = nullptr;
+  int64_t n_red_index = 0;
 };
 
 namespace {
@@ -176,7 +191,9 @@ gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
     fail(c, GCRE_ERR_RANGE, "path set too large for 32-bit row addressing");
     return nullptr;
   }
-  auto* ps = new gcre_pathset{c, nrows, nullptr, nullptr, nullptr, {}};
+  auto* ps = new gcre_pathset{};
+  ps->ctx = c;
+  ps->nrows = nrows;
   const size_t bytes = (size_t)std::max<int64_t>(nrows, 1) * c->g.S * sizeof(uint64_t);
   if (hipMalloc((void**)&ps->d_rows, bytes) != hipSuccess) {
     fail(c, GCRE_ERR_DEVICE, "hipMalloc failed for a path set of " + std::to_string(bytes) + " bytes");
@@ -209,7 +226,15 @@ int build_transposed_masks(gcre_ctx* c) {
   HIP_TRY(c, hipMemsetAsync(c->d_mt, 0, bytes, c->stream));
   HIP_TRY(c, launch_build_mt(c->d_masks, 2 * g.Wp, g.Kpad, nkt, mt_rows, c->d_mt, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->mask_epoch++;   // every count plane built so far belongs to the old masks
   return GCRE_OK;
+}
+
+void drop_planes(const gcre_pathset* ps) {
+  if (ps->d_planes) (void)hipFree(ps->d_planes);
+  ps->d_planes = nullptr;
+  ps->plane_groups = 0;
+  ps->planes_valid = false;
 }
 
 void drop_lists(const gcre_pathset* ps) {
@@ -218,6 +243,9 @@ void drop_lists(const gcre_pathset* ps) {
   ps->d_loff = nullptr;
   ps->d_lidx = nullptr;
   ps->h_loff.clear();
+  ps->max_bits = 0;
+  ps->max_known = false;
+  drop_planes(ps);
 }
 
 // CSR bit lists of a path set (method 1: one list per row): offsets on the host by prefix sum, entries on the device
@@ -236,7 +264,11 @@ int ensure_lists(gcre_ctx* c, const gcre_pathset* ps) {
   (void)hipFree(d_cnt);
   if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("row lists: ") + hipGetErrorString(e));
   std::vector<uint64_t> off((size_t)n + 1, 0);
-  for (int64_t r = 0; r < n; r++) off[(size_t)r + 1] = off[(size_t)r] + cnt[(size_t)r];
+  uint32_t longest = 0;
+  for (int64_t r = 0; r < n; r++) {
+    off[(size_t)r + 1] = off[(size_t)r] + cnt[(size_t)r];
+    longest = std::max(longest, cnt[(size_t)r]);
+  }
   const uint64_t total = off[(size_t)n];
   HIP_TRY(c, hipMalloc((void**)&ps->d_loff, off.size() * 8));
   HIP_TRY(c, hipMalloc((void**)&ps->d_lidx, (size_t)(total + 16) * 4));
@@ -250,6 +282,69 @@ int ensure_lists(gcre_ctx* c, const gcre_pathset* ps) {
     return fail(c, GCRE_ERR_DEVICE, std::string("row lists: ") + hipGetErrorString(e));
   }
   ps->h_loff = std::move(off);
+  ps->max_bits = longest;
+  ps->max_known = true;
+  return GCRE_OK;
+}
+
+// largest number of carriers a row of the set can have (from its lists, or from the join that produced it)
+uint32_t row_max(const gcre_ctx* c, const gcre_pathset* ps) {
+  return ps->max_known ? ps->max_bits : (uint32_t)(64 * c->g.Wp);
+}
+
+int plane_groups_for(uint32_t max_count) {
+  int bits = 1;
+  while (bits < 16 && (max_count >> bits) != 0) bits++;
+  return std::max(2, (bits + 3) / 4);
+}
+
+bool planes_current(const gcre_ctx* c, const gcre_pathset* ps) {
+  return ps->d_planes && ps->planes_valid && ps->planes_epoch == c->mask_epoch;
+}
+
+size_t plane_bytes(const gcre_ctx* c, int64_t nrows, int groups) {
+  const size_t nkt = (size_t)((c->g.K + kSparseTile - 1) / kSparseTile);
+  return (size_t)std::max<int64_t>(nrows, 1) * c->g.method * nkt * (size_t)groups * 1024;
+}
+
+// room for `bytes` more on the device, leaving a quarter of what is free for the scratch of the join itself
+bool planes_fit(size_t bytes) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  return bytes < free_b - free_b / 4;
+}
+
+// allocate (not fill) the plane array of a set; false when it does not fit
+bool alloc_planes(gcre_ctx* c, const gcre_pathset* ps, int groups) {
+  if (ps->d_planes && ps->plane_groups == groups) {
+    ps->planes_valid = false;
+    return true;
+  }
+  drop_planes(ps);
+  const size_t bytes = plane_bytes(c, ps->nrows, groups);
+  if (!planes_fit(bytes)) return false;
+  if (hipMalloc((void**)&ps->d_planes, bytes) != hipSuccess) {
+    ps->d_planes = nullptr;
+    (void)hipGetLastError();
+    return false;
+  }
+  ps->plane_groups = groups;
+  return true;
+}
+
+// count planes of a path set from its bit lists (sets that were not produced by a kept join on this epoch).
+// Returns GCRE_OK with planes_current() false when the planes do not fit in device memory.
+int ensure_planes(gcre_ctx* c, const gcre_pathset* ps) {
+  if (planes_current(c, ps)) return GCRE_OK;
+  if (int rc = ensure_lists(c, ps)) return rc;
+  const int groups = plane_groups_for(ps->max_bits);
+  if (!alloc_planes(c, ps, groups)) return GCRE_OK;
+  const Geometry& g = c->g;
+  const int nkt = (g.K + kSparseTile - 1) / kSparseTile;
+  HIP_TRY(c, launch_build_planes(c->d_mt, (uint32_t)(64 * g.Wp + 1), nkt, ps->d_loff, ps->d_lidx, ps->nrows * g.method,
+                                 groups, ps->d_planes, c->stream));
+  ps->planes_epoch = c->mask_epoch;
+  ps->planes_valid = true;
   return GCRE_OK;
 }
 
@@ -367,7 +462,7 @@ struct JoinPlan {
 void free_uids(gcre_uids* u) {
   if (!u) return;
   if (u->ctx && u->ctx->stream) (void)hipStreamSynchronize(u->ctx->stream);
-  for (void* p : {(void*)u->d_path_idx, (void*)u->d_location, (void*)u->d_signs})
+  for (void* p : {(void*)u->d_path_idx, (void*)u->d_location, (void*)u->d_signs, (void*)u->d_red_index})
     if (p) (void)hipFree(p);
   for (auto& sc : u->seg_cache)
     if (sc.d_segs) (void)hipFree(sc.d_segs);
@@ -377,7 +472,13 @@ void free_uids(gcre_uids* u) {
 // validation that does not need the path sets (join_base.cpp:198-200 checks the rest in run_join)
 gcre_uids* make_uids(gcre_ctx* c, int path_length, const int32_t* uid_count, const int64_t* uid_location,
                      int64_t n_uids, const int32_t* signs, int64_t n_signs) {
-  auto* u = new gcre_uids{c, path_length, n_uids, n_signs, 0, -1, -1, nullptr, nullptr, nullptr, {}, {}};
+  auto* u = new gcre_uids{};
+  u->ctx = c;
+  u->path_length = path_length;
+  u->n_uids = n_uids;
+  u->n_signs = n_signs;
+  u->max_loc = -1;
+  u->max_idx = -1;
   std::vector<int64_t>& path_idx = u->h_path_idx;
   path_idx.assign((size_t)n_uids + 1, 0);
   for (int64_t i = 0; i < n_uids; i++) {
@@ -453,6 +554,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   std::vector<Candidate> cands;
   c->prof = gcre_profile{};
   double select_ms = 0;
+  bool keep_planes_done = false;
+  uint32_t keep_max_tot = 0;
 
   if (P > 0) {
     // segments: rows outside the shard are only materialised (when kept); the shard is scored
@@ -488,6 +591,35 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       const double up = (double)uids_in(first, count);
       return 8.0 * g.W * g.method * (up + (double)count) + 8.0 * g.W * g.K + 4.0 * g.K + 24.0 * up;
     };
+    // ---- inclusion-exclusion form (gcre_ie.hip): operands and their count planes, once per join ----
+    const bool sparse_ok = sparse_enabled(c) && c->d_mt != nullptr;
+    const bool want_ie = sparse_ok && (c->null_kernel == 0 || c->null_kernel == 3);
+    const int nkt_sp = (g.K + kSparseTile - 1) / kSparseTile;
+    bool hinted = want_ie && u.red && u.red->ctx == c && u.d_red_index && u.n_red_index > u.max_loc;
+    const gcre_pathset* red = nullptr;
+    bool have_pz = false, have_p0 = false, res_planes = false, res_planes_ok = false;
+    uint32_t join_max_tot = 0;
+    bool ie_ran = false;
+    auto prepare_z = [&]() -> int {
+      red = hinted ? u.red : jp.p1;
+      if (int rc = ensure_lists(c, red)) return rc;
+      if (int rc = ensure_planes(c, red)) return rc;
+      have_pz = planes_current(c, red);
+      return GCRE_OK;
+    };
+    if (want_ie) {
+      if (int rc = prepare_z()) return rc;
+      if (int rc = ensure_planes(c, jp.p0)) return rc;     // no-op when a kept join left them behind
+      have_p0 = planes_current(c, jp.p0);
+      if (!have_p0)
+        if (int rc = ensure_lists(c, jp.p0)) return rc;
+      if (keep) {
+        // carriers of a joined row <= carriers(paths0 row) + carriers(added row); <= padded patient count
+        const uint32_t bound = std::min<uint32_t>((uint32_t)(64 * g.Wp), row_max(c, jp.p0) + row_max(c, red));
+        res_planes = alloc_planes(c, jp.res, plane_groups_for(bound));
+        res_planes_ok = res_planes;
+      }
+    }
     for (const Seg& sg : segs) {
       for (int64_t cb = sg.b; cb < sg.e; cb += chunk_cap) {
         const int64_t n = std::min(chunk_cap, sg.e - cb);
@@ -519,19 +651,116 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         sa.count = n;
         sa.S = g.S;
         sa.Wp = g.Wp;
-        const bool use_sparse = sg.score && sparse_enabled(c) && c->d_mt != nullptr;
-        if (use_sparse) {
-          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 4, st));
+        const bool use_ie = want_ie && (sg.score || res_planes);
+        const bool use_sparse = sg.score && sparse_ok && !want_ie;
+        if (use_sparse || use_ie) {
+          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 16, st));
           sa.max_tot = c->d_max_tot;
           HIP_TRY(c, c->d_dcnt.reserve((size_t)n * g.method));
           sa.dcnt = c->d_dcnt.p;
         }
+        if (use_ie) {
+          HIP_TRY(c, c->d_rowz.reserve(cap));
+          sa.pz = red->d_rows;
+          sa.zindex = hinted ? u.d_red_index : nullptr;
+          sa.rowz = c->d_rowz.p;
+          sa.bad = c->d_max_tot + 1;
+          sa.ie_bias = have_pz ? 8 : -1;
+        }
         HIP_TRY(c, launch_stats(sa, g.method, st));
         HIP_TRY(c, hipEventRecord(e1, st));
         c->ev_stats.emplace_back(e0, e1);
+        if (!sg.score && !(use_ie && g.K > 0)) continue;
+
+        bool ran_sparse = false, redo = false;
+        if (g.K > 0 && use_ie) do {
+          const uint32_t zoff = (uint32_t)(64 * g.Wp) << 8;
+          const int64_t nl = n * g.method;
+          HIP_TRY(c, c->d_doff.reserve((size_t)nl + 1));
+          HIP_TRY(c, c->d_scan.reserve((size_t)(nl + 1023) / 1024 + 2));
+          HIP_TRY(c, launch_scan_u32_u64(c->d_dcnt.p, nl, c->d_doff.p, c->d_scan.p, st));
+          uint32_t flags[4] = {0, 0, 0, 0};   // max carriers, hint broken, overlap-mode lists
+          uint64_t n_list = 0;
+          HIP_TRY(c, hipMemcpyAsync(flags, c->d_max_tot, 16, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(&n_list, c->d_doff.p + nl, 8, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipStreamSynchronize(st));
+          const uint32_t max_tot = flags[0];
+          join_max_tot = std::max(join_max_tot, max_tot);
+          if (flags[1] != 0) {
+            // the hint does not describe this join: run it on paths1 itself (identity map) from this chunk on
+            if (!hinted) return fail(c, GCRE_ERR_DEVICE, "internal: joined path differs from paths0 | paths1");
+            hinted = false;
+            if (int rc = prepare_z()) return rc;
+            redo = true;
+            break;
+          }
+          const int64_t nseg_est = std::max<int64_t>(uids_in(cb, n), 1);
+          if (c->null_kernel == 0 && sg.score) {
+            // auto: dense bit vectors (or tiny K) are cheaper on the AND+BCNT kernel (DESIGN.md "Kernel choice")
+            const double base = have_p0 ? 0.0 : (double)row_max(c, jp.p0) * g.method * (double)nseg_est / (double)n;
+            const double entries = (double)n_list / (double)n + base + 10.0 * g.method;
+            const double ie_cost = entries * nkt_sp * 15.0;
+            const double dense_cost = 2.0 * g.Wp * g.method * (double)g.K * 2.0 / 65.0;
+            if (ie_cost >= dense_cost) { res_planes_ok = false; break; }
+          }
+          HIP_TRY(c, c->d_dlist.reserve((size_t)n_list + 16));
+          HIP_TRY(c, launch_ie_fill((const uint32_t*)jp.p0->d_rows, 2 * g.S, 2 * g.Wp, g.method, c->d_row0.p, c->d_rowz.p, n,
+                                    red->d_loff, red->d_lidx, c->d_doff.p, zoff, c->d_dlist.p, st));
+          int planes = 5;
+          while (planes < 16 && (max_tot >> planes) != 0) planes++;
+          IeArgs ia{};
+          if (int rc = sparse_segments(c, u, cb, n, &ia.segs, &ia.nsegs)) return rc;
+          ia.mt = c->d_mt;
+          ia.tot = c->d_tot.p;
+          ia.rowz = c->d_rowz.p;
+          ia.planes0 = have_p0 ? jp.p0->d_planes : nullptr;
+          ia.g0 = have_p0 ? jp.p0->plane_groups : 0;
+          ia.planesz = have_pz ? red->d_planes : nullptr;
+          ia.gz = have_pz ? red->plane_groups : 0;
+          ia.loff0 = jp.p0->d_loff;
+          ia.lidx0 = jp.p0->d_lidx;
+          ia.doff = c->d_doff.p;
+          ia.dlist = c->d_dlist.p;
+          ia.t32 = c->d_t32;
+          ia.d64 = c->d_dmax;
+          ia.ladder = c->d_ladder;
+          ia.ladder_stride = g.TD;
+          ia.prune = (g.method == 1 && c->d_ladder && c->ie_prune) ? 1 : 0;
+          ia.null_bits = c->d_null;
+          ia.planes_out = res_planes ? jp.res->d_planes : nullptr;
+          ia.go = res_planes ? jp.res->plane_groups : 0;
+          ia.out_first = cb;
+          ia.score_begin = 0;
+          ia.score_end = sg.score ? (uint32_t)n : 0u;
+          ia.nkt = nkt_sp;
+          ia.K = g.K;
+          ia.mt_rows = (uint32_t)(64 * g.Wp + 1);
+          ia.zoff = zoff;
+          c->prof.null_row_loads += ((have_p0 ? 0.0 : (double)row_max(c, jp.p0) * g.method * (double)nseg_est) + (double)n_list) * nkt_sp;
+          int dev_cus = 256;
+          (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+          const int wpc = std::min(c->sparse_waves_per_cu, ie_max_waves_per_cu(g.method, planes));
+          ia.waves_per_xcd = std::max(4, (dev_cus * wpc / 8 / 4) * 4);
+          hipEvent_t n0 = get_event(c), n1 = get_event(c);
+          HIP_TRY(c, hipEventRecord(n0, st));
+          HIP_TRY(c, launch_null_ie(ia, g.method, planes, st));
+          HIP_TRY(c, hipEventRecord(n1, st));
+          c->ev_null.emplace_back(n0, n1);
+          if (sg.score) {
+            c->prof.null_kernel_launches++;
+            c->prof.null_alg_bytes += alg_bytes(cb, n);
+          }
+          c->prof.ie_launches++;
+          c->prof.ie_overlap_lists += flags[2];
+          ie_ran = true;
+          ran_sparse = true;
+        } while (false);
+        if (redo) {
+          cb -= chunk_cap;   // same chunk again, now against paths1 itself
+          continue;
+        }
         if (!sg.score) continue;
 
-        bool ran_sparse = false;
         if (g.K > 0 && use_sparse) do {
           // inspector (once per chunk, shared by all permutation tiles): per joined path the bits paths1 adds
           // on top of paths0 -> offsets by a device scan of the counts k_stats left, entries by k_delta_fill
@@ -669,6 +898,18 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         c->prof.paths += n;
       }
     }
+    keep_planes_done = res_planes && res_planes_ok && g.K > 0;
+    keep_max_tot = join_max_tot;
+    if (ie_ran && hinted) c->prof.ie_hinted_joins++;
+    if (ie_ran && have_p0) c->prof.ie_plane_joins++;
+  }
+
+  if (keep_planes_done) {
+    // the kept rows leave with their count planes: the next level's N0 (gcre_ie.hip)
+    jp.res->planes_epoch = c->mask_epoch;
+    jp.res->planes_valid = true;
+    jp.res->max_bits = (keep_max_tot + 3u) & ~3u;
+    jp.res->max_known = true;
   }
 
   // ---- null maxima: first K entries, f32 (methods.h:101-102; format_result, join_base.cpp:144-146) ----
@@ -771,12 +1012,13 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   if (const char* e = std::getenv("GCRE_CHUNK_PATHS")) c->chunk_paths = std::max<long long>(64, std::atoll(e));
   if (const char* e = std::getenv("GCRE_NULL_BLOCKS_PER_CU")) c->null_blocks_per_cu = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("GCRE_NULL_KERNEL"))
-    c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : 0;
+    c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : !std::strcmp(e, "ie") ? 3 : 0;
+  if (const char* e = std::getenv("GCRE_IE_PRUNE")) c->ie_prune = std::atoi(e) != 0;
   if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));
 
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_case_mask, (size_t)g.Wp * 8) == hipSuccess;
-  ok = ok && hipMalloc((void**)&c->d_max_tot, 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_max_tot, 16) == hipSuccess;
   if (ok && g.Kpad > 0) {
     ok = hipMalloc((void**)&c->d_masks, (size_t)2 * g.Wp * g.Kpad * 4) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_null, (size_t)g.Kpad * 4) == hipSuccess;
@@ -801,7 +1043,7 @@ void gcre_destroy(gcre_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void* p : {(void*)c->d_case_mask, (void*)c->d_masks, (void*)c->d_t32, (void*)c->d_dvt, (void*)c->d_dmax,
-                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot})
+                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot, (void*)c->d_ladder})
     if (p) (void)hipFree(p);
   for (auto* b : {&c->d_row0, &c->d_row1, &c->d_tot, &c->d_cases, &c->d_ctrls, &c->d_sel, &c->d_small, &c->d_chunk,
                   &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})
@@ -812,6 +1054,7 @@ void gcre_destroy(gcre_ctx* c) {
   c->d_scan.release();
   c->d_dcnt.release();
   c->d_dlist.release();
+  c->d_rowz.release();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -858,6 +1101,11 @@ int gcre_set_value_table(gcre_ctx* c, const double* table, int nrow, int ncol, i
     }
     HIP_TRY(c, hipMalloc((void**)&c->d_t32, NT * 4));
     HIP_TRY(c, hipMemcpy(c->d_t32, t32.data(), NT * 4, hipMemcpyHostToDevice));
+    if (TD <= 65536) {   // counts fit the 16-bit bounds of a ladder entry
+      if (!c->d_ladder) HIP_TRY(c, hipMalloc((void**)&c->d_ladder, (size_t)kLadderLevels * TD * 4));
+      HIP_TRY(c, launch_build_ladder(c->d_t32, (int)TD, c->d_ladder, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
   } else {
     // compute_value_table_max, methods.h:110-118: max(vt[r][c], vt[c][r]) with std::max semantics
     std::vector<double> dmax(NT);
@@ -1118,6 +1366,30 @@ gcre_uids* gcre_uids_create(gcre_ctx* c, int path_length, const int32_t* uid_cou
 
 int64_t gcre_uids_total_paths(const gcre_uids* u) { return u ? u->total : GCRE_ERR_ARG; }
 
+int gcre_uids_set_reduced(gcre_uids* u, const gcre_pathset* reduced, const int32_t* index, int64_t n) {
+  if (!u) return GCRE_ERR_ARG;
+  gcre_ctx* c = u->ctx;
+  (void)hipSetDevice(c->device);
+  if (u->d_red_index) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(u->d_red_index);
+  }
+  u->d_red_index = nullptr;
+  u->red = nullptr;
+  u->n_red_index = 0;
+  if (!reduced) return GCRE_OK;
+  if (reduced->ctx != c || !index || n < 0) return fail(c, GCRE_ERR_ARG, "bad reduced operand");
+  for (int64_t i = 0; i < n; i++)
+    if ((int64_t)((uint32_t)index[i] & 0x7fffffffu) >= reduced->nrows) return fail(c, GCRE_ERR_RANGE, "reduced index out of range");
+  if (n == 0) return GCRE_OK;
+  HIP_TRY(c, hipMalloc((void**)&u->d_red_index, (size_t)n * 4));
+  HIP_TRY(c, hipMemcpyAsync(u->d_red_index, index, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  u->red = reduced;
+  u->n_red_index = n;
+  return GCRE_OK;
+}
+
 void gcre_uids_free(gcre_uids* u) {
   if (u && u->ctx) (void)hipSetDevice(u->ctx->device);
   free_uids(u);
@@ -1186,6 +1458,10 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     total.scores += c->prof.scores;
     total.null_alg_bytes += c->prof.null_alg_bytes;
     total.null_row_loads += c->prof.null_row_loads;
+    total.ie_launches += c->prof.ie_launches;
+    total.ie_overlap_lists += c->prof.ie_overlap_lists;
+    total.ie_hinted_joins += c->prof.ie_hinted_joins;
+    total.ie_plane_joins += c->prof.ie_plane_joins;
   };
 
   int rc = gcre_set_value_table(c, in->value_table, in->vt_rows, in->vt_cols, in->vt_col_major);   // wrapper.cpp:213
@@ -1207,10 +1483,17 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     for (int64_t i = 0; i < lv.n_uids; i++) t += std::max(lv.uid_count[i], 0);
     return t;
   };
+  // red/red_index: what the join really adds to paths0 (gcre_uids_set_reduced) -- checked per join, never trusted
   auto join = [&](int plen, const gcre_level& lv, const gcre_pathset* p0, const gcre_pathset* p1, gcre_pathset* res,
-                  gcre_result* o) -> int {
+                  gcre_result* o, const gcre_pathset* red = nullptr, const int32_t* red_index = nullptr,
+                  int64_t n_red = 0) -> int {
     gcre_uids* u = make_uids(c, plen, lv.uid_count, lv.uid_location, lv.n_uids, lv.signs, lv.n_signs);
     if (!u) return c->last_code;
+    if (red && red_index && n_red >= p1->nrows) {
+      bool in_range = true;
+      for (int64_t i = 0; i < n_red && in_range; i++) in_range = (int64_t)((uint32_t)red_index[i] & 0x7fffffffu) < red->nrows;
+      if (in_range && gcre_uids_set_reduced(u, red, red_index, n_red) != GCRE_OK) { free_uids(u); return c->last_code; }
+    }
     JoinPlan jp{u, p0, p1, res, false, 0, 0, nullptr};
     gcre_result tmp;
     int r = run_join(c, jp, &tmp);
@@ -1244,7 +1527,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     gcre_pathset* input1 = gcre_pathset_select(c, parsed1, in->data_inds[0], in->n_data_inds[0]);
     PP_REQUIRE(input1);
     temps.push_back(input1);
-    PP_TRY(join(1, in->level[0], zero1, input1, paths1, nullptr));   // result discarded, wrapper.cpp:233
+    PP_TRY(join(1, in->level[0], zero1, input1, paths1, nullptr, parsed1, in->data_inds[0], in->n_data_inds[0]));   // result discarded, wrapper.cpp:233
 
     if (!c->quiet) std::printf("Processing Path Length: %d\n", 1);
     gcre_pathset* zero2 = gcre_pathset_zeros(c, in->n_data_inds[1]);
@@ -1255,7 +1538,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     gcre_pathset* input2 = gcre_pathset_select(c, parsed2, in->data_inds[1], in->n_data_inds[1]);
     PP_REQUIRE(input2);
     temps.push_back(input2);
-    PP_TRY(join(1, in->level[1], zero2, input2, nullptr, &out[0]));
+    PP_TRY(join(1, in->level[1], zero2, input2, nullptr, &out[0], parsed2, in->data_inds[1], in->n_data_inds[1]));
   }
   if (L >= 2) {   // wrapper.cpp:246-253
     if (!c->quiet) std::printf("Processing Path Length: %d\n", 2);
@@ -1265,7 +1548,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
     PP_REQUIRE(input);
     temps.push_back(input);
-    PP_TRY(join(2, in->level[2], paths1, input, paths2, &out[1]));
+    PP_TRY(join(2, in->level[2], paths1, input, paths2, &out[1], parsed1, in->data_inds[3], in->n_data_inds[3]));
   }
   if (L >= 3) {   // wrapper.cpp:255-262
     if (!c->quiet) std::printf("Processing Path Length: %d\n", 3);
@@ -1274,15 +1557,34 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
     PP_REQUIRE(input);
     temps.push_back(input);
-    PP_TRY(join(3, in->level[3], paths2, input, paths3, &out[2]));
+    PP_TRY(join(3, in->level[3], paths2, input, paths3, &out[2], parsed1, in->data_inds[3], in->n_data_inds[3]));
   }
   if (L >= 4) {   // wrapper.cpp:264-269
     if (!c->quiet) std::printf("Processing Path Length: %d\n", 4);
-    PP_TRY(join(4, in->level[4], paths3, paths2, nullptr, &out[3]));
+    // paths2[loc] = (c, d) with c already on paths3[idx]: the join adds gene d = the data row level 2 joined at loc
+    // (signed method: level 2 put d into the (-) half when the relation's sign is not 1, gcre.h:71-81 -> bit 31)
+    std::vector<int32_t> added((size_t)in->n_data_inds[3]);
+    for (int64_t i = 0; i < in->n_data_inds[3]; i++) {
+      const bool neg = c->g.method == 2 && i < in->level[2].n_signs && in->level[2].signs[i] != 1;
+      added[(size_t)i] = (int32_t)((uint32_t)in->data_inds[3][i] | (neg ? 0x80000000u : 0u));
+    }
+    PP_TRY(join(4, in->level[4], paths3, paths2, nullptr, &out[3], parsed1, added.data(), (int64_t)added.size()));
   }
   if (L >= 5) {   // wrapper.cpp:271-276
     if (!c->quiet) std::printf("Processing Path Length: %d\n", 5);
-    PP_TRY(join(5, in->level[5], paths3, paths3, nullptr, &out[4]));
+    // paths3[loc] = (c, d, e) with c on paths3[idx]: the join adds the 2-gene path (d, e) = paths2[second relation],
+    // and the second relation of joined path q of level 3 is the paths1 row it joined: location3[uid] + offset
+    std::vector<int32_t> second;
+    {
+      const gcre_level& l3 = in->level[3];
+      for (int64_t i = 0; i < l3.n_uids; i++) {
+        // signed method: (d, e) sits in paths3[loc] with both halves swapped when the relation (c, d) is not positive
+        const bool neg = c->g.method == 2 && i < l3.n_signs && l3.signs[i] != 1;
+        for (int32_t t = 0; t < l3.uid_count[i]; t++)
+          second.push_back((int32_t)((uint32_t)(l3.uid_location[i] + t) | (neg ? 0x80000000u : 0u)));
+      }
+    }
+    PP_TRY(join(5, in->level[5], paths3, paths3, nullptr, &out[4], paths2, second.data(), (int64_t)second.size()));
   }
   if (!c->quiet) std::printf("[success]\n");   // wrapper.cpp:278
   cleanup();

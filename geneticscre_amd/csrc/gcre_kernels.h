@@ -88,7 +88,44 @@ constexpr int kSparseTile = 2048;
 constexpr int kSparseSegMax = 64;
 hipError_t launch_null_sparse(const SparseArgs& a, int method, int planes, hipStream_t stream);
 int sparse_max_waves_per_cu(int method, int planes);   // resident waves per CU of the variant chosen for `planes` counter planes
-// exclusive prefix sum of n u32 counts into n+1 u64 offsets (scratch: >= (n+1023)/1024 + 1 u64)
+// ---- inclusion-exclusion null kernel on count planes (gcre_ie.hip) ----
+constexpr int kLadderLevels = 256;   // pruning thresholds j / kLadderPerUnit, j = 0 .. kLadderLevels-1
+constexpr int kLadderPerUnit = 8;
+struct IeArgs {
+  const uint32_t* mt;        // transposed masks, as SparseArgs
+  const uint32_t* tot;       // carriers per joined path (and half) of the launch
+  const uint32_t* rowz;      // per joined path: row of the reduced operand | swap << 31
+  const SparseSeg* segs;
+  const uint32_t* planes0;   // count planes of paths0 [row*M+h][nkt][g0][64][4], or nullptr: stream loff0/lidx0
+  const uint32_t* planesz;   // count planes of the reduced operand [row*M+h][nkt][gz][64][4] (mode-1 paths)
+  const uint64_t* loff0;
+  const uint32_t* lidx0;
+  const uint64_t* doff;      // [count*M+1] list offsets (multiples of 4); bit 0 = mode: 0 delta list, 1 overlap list
+  const uint32_t* dlist;
+  const float* t32;
+  const double* d64;
+  const uint32_t* ladder;    // [kLadderLevels][ladder_stride] hi << 16 | lo (method 1)
+  uint32_t* null_bits;
+  uint32_t* planes_out;      // optional: planes of the joined paths [(out_first+q)*M+h][nkt][go][64][4]
+  int64_t out_first;
+  int64_t nsegs;
+  uint32_t score_begin, score_end;   // joined paths of the launch outside [begin, end) only produce planes
+  int nkt, waves_per_xcd, K;
+  int g0, gz, go;            // plane groups (4 planes each) of the three plane arrays
+  int prune;                 // method 1: test counts against the ladder before the table lookup
+  int ladder_stride;         // = number of table diagonals
+  uint32_t mt_rows, zoff;
+};
+hipError_t launch_null_ie(const IeArgs& a, int method, int planes, hipStream_t stream);
+int ie_max_waves_per_cu(int method, int planes);
+hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, const uint64_t* loff, const uint32_t* lidx,
+                               int64_t nrowhalves, int groups, uint32_t* planes, hipStream_t stream);
+hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipStream_t stream);
+hipError_t launch_ie_fill(const uint32_t* p0, int S32, int W32p, int method, const uint32_t* row0, const uint32_t* rowz,
+                          int64_t count, const uint64_t* loffz, const uint32_t* lidxz, const uint64_t* doff, uint32_t zoff,
+                          uint32_t* dlist, hipStream_t stream);
+// exclusive prefix sum of n u32 counts into n+1 u64 offsets; the low 2 bits of a count do not add, they are copied
+// into the low bits of its offset (list lengths are multiples of 4, bit 0 carries the IE list mode) (scratch: >= (n+1023)/1024 + 1 u64)
 hipError_t launch_scan_u32_u64(const uint32_t* cnt, int64_t n, uint64_t* off, uint64_t* scratch, hipStream_t stream);
 // per joined path: entries of paths1's list whose bit is clear in the paths0 row, 16-padded, at dlist[doff[i]..)
 hipError_t launch_delta_fill(const uint32_t* p0, int S32, int W32p, int method, const uint32_t* row0,
@@ -126,7 +163,13 @@ struct StatsArgs {
   uint32_t* ctrls;
   uint64_t* res;               // kept rows, indexed by absolute ordinal (first + i), or nullptr
   uint32_t* max_tot;           // optional: running maximum of the carrier totals (sizes the sparse kernel's counters)
-  uint32_t* dcnt;              // optional (method 1): popcount(path1 & ~path0) rounded up to 4, per joined path (and half)
+  uint32_t* dcnt;              // optional: popcount(path1 & ~path0) rounded up to 4, per joined path (and half)
+  // inclusion-exclusion form (all optional): pz = reduced operand, zindex[row of paths1] = its row (nullptr: same row)
+  const uint64_t* pz;
+  const int32_t* zindex;
+  uint32_t* rowz;              // out: reduced row | swap << 31 per joined path
+  uint32_t* bad;               // out: set to 1 when some joined path differs from paths0 | reduced row
+  int ie_bias;                 // overlap list chosen when overlap + ie_bias < delta; negative: never
   int64_t first;
   int64_t count;
   int S;

@@ -455,29 +455,57 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
   const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
   const int Wp = a.Wp;
-  u32 wave_max_tot = 0;
+  u32 wave_max_tot = 0, wave_modes = 0;
   for (i64 i = wave; i < a.count; i += nwaves) {
     const u32 r0 = a.row0[i];
     const u32 r1raw = a.row1[i];
     const u32 r1 = r1raw & 0x7fffffffu;
     const u64* x = a.p0 + (size_t)r0 * a.S;
     const u64* y = a.p1 + (size_t)r1 * a.S;
+    // row of the reduced operand (inclusion-exclusion form); bit 31 of an index entry swaps its halves once more
+    const u32 zraw = a.zindex ? (u32)a.zindex[r1] : r1;
+    const u32 rz = zraw & 0x7fffffffu;
+    const u32 zflip = (r1raw ^ (a.zindex ? zraw : 0u)) & 0x80000000u;
     u64* out = a.res ? a.res + (size_t)(a.first + i) * a.S : nullptr;
     if constexpr (M == 1) {
-      u32 cs = 0, ct = 0, dl = 0;
+      u32 cs = 0, ct = 0, dl = 0, ov = 0, px = 0, extra = 0;
+      const u64* z = a.pz ? a.pz + (size_t)rz * a.S : y;
       for (int k = lane; k < Wp; k += 64) {
-        const u64 j = x[k] | y[k];
+        const u64 xk = x[k], yk = y[k];
+        const u64 j = xk | yk;
         const u64 cm = a.case_mask[k];
         cs += __popcll(j & cm);      // methods.h:77-78
         ct += __popcll(j & ~cm);
-        dl += __popcll(y[k] & ~x[k]);   // bits paths1 adds on top of paths0 (sparse kernel's per-path list length)
+        if (a.pz) {
+          const u64 zk = z[k];
+          dl += __popcll(zk & ~xk);     // bits the reduced row adds on top of paths0 ...
+          ov += __popcll(zk & xk);      // ... and the bits it shares with it
+          px += __popcll(xk);
+          extra += __popcll(zk & ~j);
+        } else {
+          dl += __popcll(yk & ~xk);     // bits paths1 adds on top of paths0 (sparse kernel's per-path list length)
+        }
         if (out) out[k] = j;
       }
       cs = wave_sum(cs);
       ct = wave_sum(ct);
       if (a.dcnt) {
         dl = wave_sum(dl);
-        if (lane == 0) a.dcnt[i] = (dl + 3u) & ~3u;
+        if (a.pz) {
+          ov = wave_sum(ov);
+          px = wave_sum(px);
+          extra = wave_sum(extra);
+          if (lane == 0) {
+            const u32 mode = (a.ie_bias >= 0 && ov + (u32)a.ie_bias < dl) ? 1u : 0u;
+            a.dcnt[i] = (((mode ? ov : dl) + 3u) & ~3u) | mode;
+            a.rowz[i] = rz | zflip;
+            // paths0 | reduced row must be the joined path: reduced row inside it, same number of carriers
+            if (extra != 0u || px + dl != cs + ct) *a.bad = 1u;
+            wave_modes += mode;
+          }
+        } else if (lane == 0) {
+          a.dcnt[i] = (dl + 3u) & ~3u;
+        }
       }
       if (lane == 0) {
         const u32 total = cs + ct;
@@ -493,12 +521,24 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
       const u64* yp = swap ? y + Wp : y;
       const u64* yn = swap ? y : y + Wp;
       u32 case_pos = 0, ctrl_neg = 0, case_neg = 0, ctrl_pos = 0, dlp = 0, dln = 0;
+      u32 ovp = 0, ovn = 0, pxp = 0, pxn = 0, extra = 0;
+      const u64* z = a.pz ? a.pz + (size_t)rz * a.S : y;
+      const u64* zp = zflip ? z + Wp : z;
+      const u64* zn = zflip ? z : z + Wp;
       for (int k = lane; k < Wp; k += 64) {
-        const u64 bp = x[k] | yp[k];            // methods.h:164-165
-        const u64 bn = x[Wp + k] | yn[k];
+        const u64 xp = x[k], xn = x[Wp + k];
+        const u64 bp = xp | yp[k];              // methods.h:164-165
+        const u64 bn = xn | yn[k];
         const u64 cm = a.case_mask[k];
-        dlp += __popcll(yp[k] & ~x[k]);         // sparse kernel: bits path1 adds to the (+) / (-) half
-        dln += __popcll(yn[k] & ~x[Wp + k]);
+        dlp += __popcll(zp[k] & ~xp);           // bits the joined row adds to the (+) / (-) half
+        dln += __popcll(zn[k] & ~xn);
+        if (a.pz) {
+          ovp += __popcll(zp[k] & xp);
+          ovn += __popcll(zn[k] & xn);
+          pxp += __popcll(xp);
+          pxn += __popcll(xn);
+          extra += __popcll(zp[k] & ~bp) + __popcll(zn[k] & ~bn);
+        }
         case_pos += __popcll(bp & cm);          // methods.h:182-185
         ctrl_neg += __popcll(bp & ~cm);
         case_neg += __popcll(bn & ~cm);
@@ -512,7 +552,22 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
       if (a.dcnt) {
         dlp = wave_sum(dlp);
         dln = wave_sum(dln);
-        if (lane == 0) {
+        if (a.pz) {
+          ovp = wave_sum(ovp);
+          ovn = wave_sum(ovn);
+          pxp = wave_sum(pxp);
+          pxn = wave_sum(pxn);
+          extra = wave_sum(extra);
+          if (lane == 0) {
+            const u32 mp = (a.ie_bias >= 0 && ovp + (u32)a.ie_bias < dlp) ? 1u : 0u;
+            const u32 mn = (a.ie_bias >= 0 && ovn + (u32)a.ie_bias < dln) ? 1u : 0u;
+            a.dcnt[2 * i] = (((mp ? ovp : dlp) + 3u) & ~3u) | mp;
+            a.dcnt[2 * i + 1] = (((mn ? ovn : dln) + 3u) & ~3u) | mn;
+            a.rowz[i] = rz | zflip;
+            if (extra != 0u || pxp + dlp != case_pos + ctrl_neg || pxn + dln != case_neg + ctrl_pos) *a.bad = 1u;
+            wave_modes += mp + mn;
+          }
+        } else if (lane == 0) {
           a.dcnt[2 * i] = (dlp + 3u) & ~3u;
           a.dcnt[2 * i + 1] = (dln + 3u) & ~3u;
         }
@@ -531,6 +586,7 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
     }
   }
   if (a.max_tot && lane == 0 && wave_max_tot) atomicMax(a.max_tot, wave_max_tot);
+  if (a.bad && lane == 0 && wave_modes) atomicAdd(a.bad + 1, wave_modes);   // statistics: overlap-mode lists
 }
 
 hipError_t launch_stats(const StatsArgs& a, int method, hipStream_t stream) {

@@ -70,6 +70,10 @@ typedef struct {
   int64_t scores;             /* paths x iterations */
   double null_alg_bytes;      /* algorithmic HBM bytes of the null kernel launches */
   double null_row_loads;      /* sparse kernel: mask-row loads issued (list entries x permutation tiles); 0 = dense kernel */
+  int64_t ie_launches;        /* launches of the inclusion-exclusion kernel (gcre_ie.hip) */
+  int64_t ie_overlap_lists;   /* joined-path halves scored as N0 + Nz - overlap (the rest streamed their delta list) */
+  int64_t ie_hinted_joins;    /* joins that ran on a verified gcre_uids_set_reduced operand */
+  int64_t ie_plane_joins;     /* joins whose paths0 count planes were already resident */
 } gcre_profile;
 
 /* ---- context: JoinExec::JoinExec, src/join_base.cpp:37-59.  method 1 = unsigned, 2 = signed. ---- */
@@ -124,6 +128,18 @@ gcre_uids* gcre_uids_create(gcre_ctx* ctx, int path_length, const int32_t* uid_c
                             int64_t n_uids, const int32_t* signs, int64_t n_signs);
 int64_t gcre_uids_total_paths(const gcre_uids* uids);   /* UidRelSet::count_total_paths, gcre.h:83-88 */
 void gcre_uids_free(gcre_uids* uids);
+/* Optional speed hint, no reference counterpart (the reference walks every word of both operands, methods.h:73-88).
+ * States that for every joined path (idx, loc) of this index
+ *     paths0[idx] | paths1[loc]  ==  paths0[idx] | reduced[index[loc]]
+ * e.g. at path length 4 paths1[loc] is the 2-gene path (c, d) whose first gene c already lies on paths0[idx], so
+ * `reduced` = the per-gene rows and index[loc] = d.  The null kernel then adds the reduced row's precomputed
+ * permutation counts instead of walking paths1[loc].  The claim is checked on the device for every join
+ * (reduced row inside the joined row, equal carrier totals); a join for which it fails silently runs on paths1.
+ * `index` has one entry per row of paths1 (n >= largest location + 1), values in [0, rows(reduced)); bit 31 of an
+ * entry set = (signed method) the reduced row enters with its (+)/(-) halves swapped relative to how paths1[loc]
+ * enters (UidRelSet::need_flip, gcre.h:71-81).
+ * The caller keeps `reduced` alive while the index is used.  reduced == NULL removes the hint. */
+int gcre_uids_set_reduced(gcre_uids* uids, const gcre_pathset* reduced, const int32_t* index, int64_t n);
 int gcre_join_uids(gcre_ctx* ctx, const gcre_uids* uids, const gcre_pathset* paths0, const gcre_pathset* paths1,
                    gcre_pathset* res, const gcre_join_opts* opts, gcre_result* out);
 

@@ -1,0 +1,143 @@
+"""The inclusion-exclusion null kernel (gcre_ie.hip): count planes, reduced-operand hints and pruned lookups must
+leave every result bit-identical to the oracle, whatever combination of them a join ends up using."""
+import numpy as np
+import pytest
+
+import oracle
+from geneticscre_amd import api, dist
+from geneticscre_amd.synth import make_problem
+from helpers import assert_same_result, small_table
+
+pytestmark = pytest.mark.gpu
+
+
+def sparse_problem(method, seed, K=300, L=5, nc=310, nt=335, genes=70, edges=260):
+    """Rare-variant shaped: 645 patients (11 words, padded to 12), every gene in <= 5 % of them."""
+    return make_problem(genes, edges, nc, nt, K, L, method=method, top_k=15, seed=seed, threshold=0.05)
+
+
+def check_levels(got, want, levels):
+    for lvl in levels:
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+@pytest.mark.parametrize("prune", ["1", "0"])
+def test_process_paths_runs_on_planes_with_verified_hints(method, prune, monkeypatch):
+    """All six joins go through k_null_ie: hints verified, paths0 planes resident from level 2 on (by-product of
+    the kept joins), and most joined paths scored as N0 + Nz - overlap."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_IE_PRUNE", prune)
+    p = sparse_problem(method, 5)
+    got = api.process_paths(p)
+    want = oracle.process_paths(p, order="canonical")
+    check_levels(got, want, range(1, 6))
+    prof = got["profile"]
+    assert prof["ie_launches"] >= 6
+    assert prof["ie_hinted_joins"] == 6
+    assert prof["ie_plane_joins"] == 6          # zero sets build theirs, kept sets inherit theirs
+    total_lists = sum(p.levels.n_paths[k] for k in ("1a", "1b", "2", "3", "4", "5")) * (2 if method == "method2" else 1)
+    # (signed method: one half of a gene row is empty -- an empty delta list, nothing to subtract)
+    assert prof["ie_overlap_lists"] > (0.5 if method == "method1" else 0.25) * total_lists
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_auto_is_the_ie_kernel_on_rare_variant_data(method):
+    p = sparse_problem(method, 6, K=2100, L=4)      # two permutation tiles, the second one partial
+    got = api.process_paths(p)
+    want = oracle.process_paths(p, order="canonical")
+    check_levels(got, want, range(1, 5))
+    assert got["profile"]["ie_launches"] >= 5 and got["profile"]["ie_overlap_lists"] > 0
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_wrong_hint_is_detected_and_ignored(method, monkeypatch):
+    """A reduced operand that does not reproduce the joined rows must change nothing: the device check fails and the
+    join runs on paths1 itself."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_CHUNK_PATHS", "256")       # the failure shows up in the first of several chunks
+    p = sparse_problem(method, 7, K=200, L=4)
+    full = oracle.process_paths(p, order="canonical")
+    ex = api.JoinExec(method, p.n_cases, p.n_ctrls, p.iterations)
+    ex.top_k = p.top_k
+    ex.set_value_table(p.value_table)
+    ex.set_permuted_cases(p.perm_cases)
+    p3, p2 = ex.from_words(full["paths3"]), ex.from_words(full["paths2"])
+    genes = ex.load(p.data1)
+    du = api.DeviceUids(ex, p.levels.uids["4"])
+    rng = np.random.default_rng(1)
+    du.set_reduced(genes, rng.integers(0, genes.size, p2.size))     # garbage
+    assert_same_result(ex.join(du, p3, p2), full["lst4"])
+    assert ex.profile()["ie_hinted_joins"] == 0 and ex.profile()["ie_launches"] > 0
+    real = np.asarray(p.levels.data_inds["3"], np.int64)             # the real one: the gene level 2 added at loc,
+    if method == "method2":                                         # in the (-) half when its relation is negative
+        real = real | ((np.asarray(p.levels.uids["2"].signs) != 1).astype(np.int64) << 31)
+    du.set_reduced(genes, real)
+    assert_same_result(ex.join(du, p3, p2), full["lst4"])
+    assert ex.profile()["ie_hinted_joins"] == 1
+    du.set_reduced(None)
+    assert_same_result(ex.join(du, p3, p2), full["lst4"])
+    assert ex.profile()["ie_hinted_joins"] == 0
+    with pytest.raises(IndexError):
+        du.set_reduced(genes, np.full(p2.size, genes.size))         # out of range
+    ex.close()
+
+
+def test_planes_are_rebuilt_when_the_masks_change(monkeypatch):
+    """Count planes belong to one set of permutation masks: new masks on the same context, same path sets."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    a = sparse_problem("method1", 8, K=150, L=3)
+    b = sparse_problem("method1", 8, K=150, L=3)
+    b.perm_cases = np.ascontiguousarray(a.perm_cases[::-1] ^ 1)     # different permutations, same data
+    b.perm_cases[:, 0] = 1
+    plan = api.ResidentPlan(a)
+    first = plan.run()
+    want_a = oracle.process_paths(a, order="canonical")
+    for name, lvl in (("1b", 1), ("2", 2), ("3", 3)):
+        assert_same_result(first[name], want_a[f"lst{lvl}"])
+    plan.ex.set_permuted_cases(b.perm_cases)
+    second = plan.run()
+    want_b = oracle.process_paths(b, order="canonical")
+    for name, lvl in (("1b", 1), ("2", 2), ("3", 3)):
+        assert_same_result(second[name], want_b[f"lst{lvl}"])
+    assert not np.array_equal(first["3"].null, second["3"].null)
+    plan.close()
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_sharded_plan_keeps_planes_for_every_row(method, monkeypatch):
+    """Two ranks' worth of shards on one GPU: kept levels are scored per shard but their count planes cover every
+    row, so the next level still runs on resident planes; merged results equal the one-shot run."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_CHUNK_PATHS", "512")
+    p = sparse_problem(method, 9, K=120, L=5)
+    want = oracle.process_paths(p, order="canonical")
+    parts = []
+    for rank in range(2):
+        plan = api.ResidentPlan(p)
+        parts.append(plan.run(rank=rank, world=2))
+        assert plan.last_profile["ie_plane_joins"] == 6
+        plan.close()
+    for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4), ("5", 5)):
+        null = np.maximum(parts[0][name].null, parts[1][name].null)
+        rows = [np.stack([r[name].scores, r[name].src, r[name].trg, r[name].cases, r[name].ctrls], axis=1) for r in parts]
+        best = dist.merge_topk(np.vstack(rows), p.top_k)
+        w = want[f"lst{lvl}"]
+        np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
+
+
+def test_arbitrary_table_prunes_exactly(monkeypatch):
+    """The pruning ladder makes no assumption about the table's shape: a table with random cells (not valley-shaped,
+    with zeros, huge values and -1 padding) gives the oracle's maxima."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    nc, nt = 150, 170
+    rng = np.random.default_rng(3)
+    table = rng.random((nc + 1, nt + 1)) * rng.choice([0.0, 1.0, 40.0, 1e6], size=(nc + 1, nt + 1))
+    table[rng.random(table.shape) < 0.05] = -1.0
+    p = make_problem(50, 170, nc, nt, 400, 4, method="method1", top_k=7, seed=12, threshold=0.06, table=table)
+    got = api.process_paths(p)
+    want = oracle.process_paths(p, order="canonical")
+    for lvl in range(1, 5):
+        np.testing.assert_array_equal(got[f"lst{lvl}"].null.view(np.uint32), want[f"lst{lvl}"].null.view(np.uint32))
+        np.testing.assert_array_equal(got[f"lst{lvl}"].scores, want[f"lst{lvl}"].scores)

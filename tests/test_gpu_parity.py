@@ -21,6 +21,16 @@ def run_both(p):
     return got, want
 
 
+def set_kernel(monkeypatch, kernel):
+    """auto = inclusion-exclusion on count planes with pruned lookups (gcre_ie.hip), dense fallback by cost;
+    ie-noprune looks every count up; sparse = bit-sliced delta streaming (gcre_sparse.hip); dense = AND+popcount."""
+    if kernel == "ie-noprune":
+        monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+        monkeypatch.setenv("GCRE_IE_PRUNE", "0")
+    else:
+        monkeypatch.setenv("GCRE_NULL_KERNEL", kernel)
+
+
 @pytest.mark.parametrize("case", json.load(open(os.path.join(GOLD, "appendix_b_expected.json")))["cases"],
                          ids=lambda c: c["name"])
 def test_appendix_b_golden(case):
@@ -38,12 +48,12 @@ def test_appendix_b_golden(case):
             assert (s, (a, b)) in ids
 
 
-@pytest.mark.parametrize("kernel", ["auto", "sparse", "dense"])
+@pytest.mark.parametrize("kernel", ["auto", "ie", "ie-noprune", "sparse", "dense"])
 @pytest.mark.parametrize("method", ["method1", "method2"])
 @pytest.mark.parametrize("n_perm", [0, 3, 100, 130, 700])
 def test_process_paths_matches_oracle(method, n_perm, kernel, monkeypatch):
     """Both forms of the null kernel (bit-sliced sparse: gcre_sparse.hip; dense AND+popcount: gcre_kernels.hip)."""
-    monkeypatch.setenv("GCRE_NULL_KERNEL", kernel)
+    set_kernel(monkeypatch, kernel)
     nc, nt = 37, 52   # patients not a multiple of 64, nCases != nControls
     p = make_problem(60, 150, nc, nt, n_perm, 5, method=method, top_k=9, seed=11 + n_perm,
                      table=small_table(nc, nt, 3))
@@ -61,12 +71,12 @@ def test_wide_masks_and_hypergeometric_table(method):
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
 
 
-@pytest.mark.parametrize("kernel", ["auto", "sparse", "dense"])
+@pytest.mark.parametrize("kernel", ["auto", "ie", "ie-noprune", "sparse", "dense"])
 @pytest.mark.parametrize("method,n_perm", [("method1", 1100), ("method2", 600), ("method1", 2500)])
 def test_baseline_mask_width_full_parity(method, n_perm, kernel, monkeypatch):
     """BASELINE configs[2] geometry (5,000 patients = 79 mask words, real -log hypergeometric table, K not a
     multiple of the permutation tile) on a network small enough for the oracle: every level bit-exact."""
-    monkeypatch.setenv("GCRE_NULL_KERNEL", kernel)
+    set_kernel(monkeypatch, kernel)
     p = make_problem(220, 800, 2500, 2500, n_perm, 4, method=method, top_k=50, seed=77)
     want = oracle.process_paths(p, order="canonical", nthreads=8)
     got = api.process_paths(p)
@@ -121,13 +131,13 @@ from helpers import fnv_rows, load_ref_cases  # noqa: E402
 REF_CASES = load_ref_cases()
 
 
-@pytest.mark.parametrize("kernel", ["auto", "sparse", "dense"])
+@pytest.mark.parametrize("kernel", ["auto", "ie", "ie-noprune", "sparse", "dense"])
 @pytest.mark.parametrize("name,p,exp", REF_CASES, ids=[c[0] for c in REF_CASES])
 def test_hip_matches_reference_scoring_code(name, p, exp, kernel, monkeypatch):
     """The HIP path against goldens printed by the reference's own scoring code (oracle/ref_partial): score values,
     counts and f32 null maxima bit-exact at every level; ids wherever the score is not tied (the reference's choice
     among ties is heap-order dependent)."""
-    monkeypatch.setenv("GCRE_NULL_KERNEL", kernel)
+    set_kernel(monkeypatch, kernel)
     got = api.process_paths(p)
     every = oracle.process_paths(p, order="canonical")       # only for "is this score tied among ALL paths?"
     for lvl in range(1, p.path_length + 1):
