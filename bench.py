@@ -318,6 +318,10 @@ def main():
         },
         "roofline": roofline,
         "kernel_time_frac": null_s / elapsed if elapsed > 0 else None,
+        "phases_ms_per_step": {k: prof_acc.get(k, 0.0) / args.steps for k in
+                               ("null_kernel_ms", "stats_kernel_ms", "select_ms", "prepare_ms", "inspect_ms", "total_ms")},
+        "ie": {k: int(prof_acc.get(k, 0)) // args.steps for k in
+               ("ie_launches", "ie_overlap_lists", "ie_hinted_joins", "ie_plane_joins", "ie_lookup_tiles")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -91,7 +91,7 @@ struct gcre_ctx {
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
   DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan;
-  DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz;
+  DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz, d_ie_scratch;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
 
   gcre_profile prof{};
@@ -109,7 +109,7 @@ struct gcre_pathset {
   mutable std::vector<uint64_t> h_loff;   // host copy of the offsets (sizes the work of a sparse launch)
   mutable uint32_t max_bits = 0;          // longest list (entries incl. padding): bounds the carriers of any row
   mutable bool max_known = false;
-  // count planes for the inclusion-exclusion kernel: [row*M+h][nkt][groups][64][4] dwords, valid for one mask epoch
+  // count planes for the inclusion-exclusion kernel: [tile][row*M+h][groups][64][4] dwords, valid for one mask epoch
   mutable uint32_t* d_planes = nullptr;
   mutable int plane_groups = 0;
   mutable uint64_t planes_epoch = 0;
@@ -129,6 +129,7 @@ struct gcre_uids {
   int64_t* d_location;
   int32_t* d_signs;
   std::vector<int64_t> h_path_idx;   // host copy, for building the sparse kernel's segment tables
+  std::vector<int64_t> h_location;   // host copy: segments are ordered by the paths1 rows they join (L2 reuse of their planes)
   struct SegCache { int64_t first, count; int64_t nsegs; SparseSeg* d_segs; };
   mutable std::vector<SegCache> seg_cache;
   // optional hint (gcre_uids_set_reduced): paths0[idx] | paths1[loc] == paths0[idx] | red[red_index[loc]] for every
@@ -368,6 +369,12 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
     for (; lo < hi; lo += kSparseSegMax)
       segs.push_back(SparseSeg{(uint32_t)i, (uint32_t)(lo - first), (uint32_t)std::min<int64_t>(kSparseSegMax, hi - lo)});
   }
+  // Segments that join the same paths1 rows (all uids with the same pivot gene share `location`) run next to each
+  // other: the waves of an XCD walk a contiguous window of this table, so the planes of those rows stay in its L2.
+  // Any order gives the same maxima.
+  std::stable_sort(segs.begin(), segs.end(), [&](const SparseSeg& x, const SparseSeg& y) {
+    return u.h_location[x.row0] < u.h_location[y.row0];
+  });
   SparseSeg* d = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d, std::max<size_t>(segs.size(), 1) * sizeof(SparseSeg)));
   if (!segs.empty())
@@ -496,6 +503,7 @@ gcre_uids* make_uids(gcre_ctx* c, int path_length, const int32_t* uid_count, con
     path_idx[(size_t)i + 1] = path_idx[(size_t)i] + std::max(cnt, 0);   // uid_ref.path_idx, wrapper.cpp:128-130
   }
   u->total = path_idx[(size_t)n_uids];
+  u->h_location.assign(uid_location, uid_location + n_uids);
   hipError_t e = hipMalloc((void**)&u->d_path_idx, path_idx.size() * 8);
   if (e == hipSuccess) e = hipMalloc((void**)&u->d_location, (size_t)std::max<int64_t>(n_uids, 1) * 8);
   if (e == hipSuccess) e = hipMalloc((void**)&u->d_signs, (size_t)std::max<int64_t>(n_signs, 1) * 4);
@@ -531,7 +539,14 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   const bool keep = jp.res != nullptr && jp.res->nrows != 0;   // keep_paths = paths_res.size != 0, join_base.cpp:217
   if (jp.res && jp.res->nrows != 0 && jp.res->nrows != P)
     return fail(c, GCRE_ERR_ASSERT, "assertion: paths_res.size != total paths");
-  if (keep) drop_lists(jp.res);   // its rows are about to be rewritten
+  if (keep) {   // its rows are about to be rewritten: lists go, the plane buffer stays allocated for the new rows
+    uint32_t* planes = jp.res->d_planes;
+    const int groups = jp.res->plane_groups;
+    jp.res->d_planes = nullptr;
+    drop_lists(jp.res);
+    jp.res->d_planes = planes;
+    jp.res->plane_groups = groups;
+  }
   if (g.method == 2 && P > 0) {
     // need_flip reads signs[idx] and/or signs[loc] (gcre.h:71-81); the reference would read out of bounds
     int64_t need_signs = 0;
@@ -593,13 +608,20 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     };
     // ---- inclusion-exclusion form (gcre_ie.hip): operands and their count planes, once per join ----
     const bool sparse_ok = sparse_enabled(c) && c->d_mt != nullptr;
-    const bool want_ie = sparse_ok && (c->null_kernel == 0 || c->null_kernel == 3);
+    bool want_ie = sparse_ok && (c->null_kernel == 0 || c->null_kernel == 3);
     const int nkt_sp = (g.K + kSparseTile - 1) / kSparseTile;
     bool hinted = want_ie && u.red && u.red->ctx == c && u.d_red_index && u.n_red_index > u.max_loc;
     const gcre_pathset* red = nullptr;
     bool have_pz = false, have_p0 = false, res_planes = false, res_planes_ok = false;
     uint32_t join_max_tot = 0;
-    bool ie_ran = false;
+    bool ie_ran = false, ie_stat_pending = false;
+    auto collect_ie_stat = [&]() {
+      if (!ie_stat_pending) return;
+      uint32_t v = 0;
+      if (hipMemcpyAsync(&v, c->d_max_tot + 3, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+        c->prof.ie_lookup_tiles += v;
+      ie_stat_pending = false;
+    };
     auto prepare_z = [&]() -> int {
       red = hinted ? u.red : jp.p1;
       if (int rc = ensure_lists(c, red)) return rc;
@@ -607,19 +629,20 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       have_pz = planes_current(c, red);
       return GCRE_OK;
     };
+    const auto tp0 = std::chrono::steady_clock::now();
     if (want_ie) {
       if (int rc = prepare_z()) return rc;
       if (int rc = ensure_planes(c, jp.p0)) return rc;     // no-op when a kept join left them behind
       have_p0 = planes_current(c, jp.p0);
-      if (!have_p0)
-        if (int rc = ensure_lists(c, jp.p0)) return rc;
-      if (keep) {
+      if (!have_p0 || !have_pz) want_ie = false;   // the planes do not fit in device memory: delta streaming (gcre_sparse.hip)
+      if (want_ie && keep) {
         // carriers of a joined row <= carriers(paths0 row) + carriers(added row); <= padded patient count
         const uint32_t bound = std::min<uint32_t>((uint32_t)(64 * g.Wp), row_max(c, jp.p0) + row_max(c, red));
         res_planes = alloc_planes(c, jp.res, plane_groups_for(bound));
         res_planes_ok = res_planes;
       }
     }
+    c->prof.prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     for (const Seg& sg : segs) {
       for (int64_t cb = sg.b; cb < sg.e; cb += chunk_cap) {
         const int64_t n = std::min(chunk_cap, sg.e - cb);
@@ -654,6 +677,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         const bool use_ie = want_ie && (sg.score || res_planes);
         const bool use_sparse = sg.score && sparse_ok && !want_ie;
         if (use_sparse || use_ie) {
+          collect_ie_stat();
           HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 16, st));
           sa.max_tot = c->d_max_tot;
           HIP_TRY(c, c->d_dcnt.reserve((size_t)n * g.method));
@@ -665,7 +689,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sa.zindex = hinted ? u.d_red_index : nullptr;
           sa.rowz = c->d_rowz.p;
           sa.bad = c->d_max_tot + 1;
-          sa.ie_bias = have_pz ? 8 : -1;
+          sa.ie_bias = 8;
         }
         HIP_TRY(c, launch_stats(sa, g.method, st));
         HIP_TRY(c, hipEventRecord(e1, st));
@@ -674,6 +698,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
 
         bool ran_sparse = false, redo = false;
         if (g.K > 0 && use_ie) do {
+          const auto ti0 = std::chrono::steady_clock::now();
           const uint32_t zoff = (uint32_t)(64 * g.Wp) << 8;
           const int64_t nl = n * g.method;
           HIP_TRY(c, c->d_doff.reserve((size_t)nl + 1));
@@ -691,6 +716,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             if (!hinted) return fail(c, GCRE_ERR_DEVICE, "internal: joined path differs from paths0 | paths1");
             hinted = false;
             if (int rc = prepare_z()) return rc;
+            if (!have_pz) want_ie = false;
             redo = true;
             break;
           }
@@ -717,6 +743,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.g0 = have_p0 ? jp.p0->plane_groups : 0;
           ia.planesz = have_pz ? red->d_planes : nullptr;
           ia.gz = have_pz ? red->plane_groups : 0;
+          ia.rows0 = (uint32_t)(jp.p0->nrows * g.method);
+          ia.rowsz = (uint32_t)(red->nrows * g.method);
+          ia.rows_out = res_planes ? (uint32_t)(jp.res->nrows * g.method) : 0u;
           ia.loff0 = jp.p0->d_loff;
           ia.lidx0 = jp.p0->d_lidx;
           ia.doff = c->d_doff.p;
@@ -725,7 +754,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.d64 = c->d_dmax;
           ia.ladder = c->d_ladder;
           ia.ladder_stride = g.TD;
-          ia.prune = (g.method == 1 && c->d_ladder && c->ie_prune) ? 1 : 0;
+          ia.prune = 0;
+          ia.lad_mode = !sg.score ? 1 : (c->ie_prune ? 0 : 2);
           ia.null_bits = c->d_null;
           ia.planes_out = res_planes ? jp.res->d_planes : nullptr;
           ia.go = res_planes ? jp.res->plane_groups : 0;
@@ -736,15 +766,46 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.K = g.K;
           ia.mt_rows = (uint32_t)(64 * g.Wp + 1);
           ia.zoff = zoff;
+          if (const char* e = std::getenv("GCRE_IE_ABLATE")) {   // diagnostics: wrong results
+            ia.ablate = std::atoi(e);
+            if (ia.ablate & 16) ia.lad_mode = 1;
+          }
           c->prof.null_row_loads += ((have_p0 ? 0.0 : (double)row_max(c, jp.p0) * g.method * (double)nseg_est) + (double)n_list) * nkt_sp;
           int dev_cus = 256;
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-          const int wpc = std::min(c->sparse_waves_per_cu, ie_max_waves_per_cu(g.method, planes));
+          const int wpc = std::min(c->sparse_waves_per_cu, ie_max_waves_per_cu(g.method, planes, ia.gz, ia.planes_out != nullptr));
           ia.waves_per_xcd = std::max(4, (dev_cus * wpc / 8 / 4) * 4);
+          c->prof.inspect_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
+          {
+            // running maxima of the waves: 8 KB each, zero between launches (the kernel leaves them zero)
+            const size_t need = (size_t)8 * ia.waves_per_xcd * 2048;
+            if (need > c->d_ie_scratch.cap) {
+              HIP_TRY(c, c->d_ie_scratch.reserve(need));
+              HIP_TRY(c, hipMemsetAsync(c->d_ie_scratch.p, 0, need * 4, st));
+            }
+            ia.scratch = c->d_ie_scratch.p;
+            ia.stats = c->d_max_tot + 3;   // 4th word of the flag block: zeroed with it before k_stats ran
+          }
+          static uint64_t* d_timing = nullptr;   // diagnostics builds only (-DGCRE_IE_TIMING), GCRE_IE_TIMING=1
+          const bool timing = std::getenv("GCRE_IE_TIMING") != nullptr;
+          if (timing) {
+            if (!d_timing) HIP_TRY(c, hipMalloc((void**)&d_timing, 64));
+            HIP_TRY(c, hipMemsetAsync(d_timing, 0, 64, st));
+            ia.timing = d_timing;
+          }
           hipEvent_t n0 = get_event(c), n1 = get_event(c);
           HIP_TRY(c, hipEventRecord(n0, st));
           HIP_TRY(c, launch_null_ie(ia, g.method, planes, st));
           HIP_TRY(c, hipEventRecord(n1, st));
+          if (timing) {
+            uint64_t tmv[8] = {0};
+            HIP_TRY(c, hipMemcpyAsync(tmv, d_timing, 48, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            const double waves = 8.0 * ia.waves_per_xcd;
+            std::fprintf(stderr, "[ie timing] paths %lld out %d waves %.0f: per-wave Mcycles seg %.2f load %.2f comp(incl load) %.2f lookup %.2f exch %.2f total %.2f\n",
+                         (long long)n, ia.planes_out != nullptr, waves, tmv[0] / waves / 1e6, tmv[1] / waves / 1e6,
+                         tmv[2] / waves / 1e6, tmv[3] / waves / 1e6, tmv[4] / waves / 1e6, tmv[5] / waves / 1e6);
+          }
           c->ev_null.emplace_back(n0, n1);
           if (sg.score) {
             c->prof.null_kernel_launches++;
@@ -752,6 +813,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           }
           c->prof.ie_launches++;
           c->prof.ie_overlap_lists += flags[2];
+          ie_stat_pending = true;
           ie_ran = true;
           ran_sparse = true;
         } while (false);
@@ -898,6 +960,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         c->prof.paths += n;
       }
     }
+    collect_ie_stat();
     keep_planes_done = res_planes && res_planes_ok && g.K > 0;
     keep_max_tot = join_max_tot;
     if (ie_ran && hinted) c->prof.ie_hinted_joins++;
@@ -1055,6 +1118,7 @@ void gcre_destroy(gcre_ctx* c) {
   c->d_dcnt.release();
   c->d_dlist.release();
   c->d_rowz.release();
+  c->d_ie_scratch.release();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1102,7 +1166,7 @@ int gcre_set_value_table(gcre_ctx* c, const double* table, int nrow, int ncol, i
     HIP_TRY(c, hipMalloc((void**)&c->d_t32, NT * 4));
     HIP_TRY(c, hipMemcpy(c->d_t32, t32.data(), NT * 4, hipMemcpyHostToDevice));
     if (TD <= 65536) {   // counts fit the 16-bit bounds of a ladder entry
-      if (!c->d_ladder) HIP_TRY(c, hipMalloc((void**)&c->d_ladder, (size_t)kLadderLevels * TD * 4));
+      if (!c->d_ladder) HIP_TRY(c, hipMalloc((void**)&c->d_ladder, (size_t)(kLadderLevels + 2) * TD * 4));
       HIP_TRY(c, launch_build_ladder(c->d_t32, (int)TD, c->d_ladder, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
@@ -1462,6 +1526,9 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     total.ie_overlap_lists += c->prof.ie_overlap_lists;
     total.ie_hinted_joins += c->prof.ie_hinted_joins;
     total.ie_plane_joins += c->prof.ie_plane_joins;
+    total.ie_lookup_tiles += c->prof.ie_lookup_tiles;
+    total.prepare_ms += c->prof.prepare_ms;
+    total.inspect_ms += c->prof.inspect_ms;
   };
 
   int rc = gcre_set_value_table(c, in->value_table, in->vt_rows, in->vt_cols, in->vt_col_major);   // wrapper.cpp:213

@@ -28,9 +28,7 @@
 namespace gcre {
 
 constexpr int kIeWaves = 4;
-constexpr int kIeDiagCap = 1024;
-constexpr int kIeDiagCap2 = 512;
-constexpr int kIeRefresh = 32;      // segments between two reads of the global maxima (threshold refresh)
+constexpr int kIeRefresh = 32;      // segments between two reads of the global maxima once the thresholds have settled
 
 __device__ __forceinline__ u32 maj3(u32 a, u32 b, u32 c) { return (a & b) | ((a ^ b) & c); }
 
@@ -43,11 +41,13 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
   return v;
 }
 
-// L = counter planes of the joined paths, a multiple of 4.
+__device__ __forceinline__ u32 rdlane(u32 v, u32 t) { return (u32)__builtin_amdgcn_readlane((int)v, (int)t); }
+
+// L = counter planes of the joined paths, a multiple of 4.  No LDS, few registers: the kernel lives on occupancy
+// (the per-path critical path is: 8 mask-row loads + the added row's planes -> ~100 bit operations -> compare).
 template <int M, int L>
-__global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
+__global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M == 1 ? 4 : 2))) void k_null_ie(const IeArgs a) {
   static_assert(L % 4 == 0 && L >= 8 && L <= 16, "planes come in groups of 4");
-  __shared__ __attribute__((aligned(8))) u32 diag_lds[kIeWaves][kIeDiagCap];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int xcd = blockIdx.x & 7;
@@ -55,54 +55,57 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
   const i64 wx = a.waves_per_xcd;
   const i64 slices = 8 * wx;
   const u32 lane4 = (u32)lane * 4u;
-  u32* dl = diag_lds[wave];
+  // the wave's running maxima live in a private 8 KB strip of global memory (L2-resident), [q][lane]: they are only
+  // touched on the rare path that survives the pruning test
+  u32* scr = a.scratch + ((size_t)blockIdx.x * kIeWaves + wave) * 2048 + lane;
 
   const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
   const u64 GCRE_CONSTANT* loff0 = (const u64 GCRE_CONSTANT*)a.loff0;
   const u32 GCRE_CONSTANT* lidx0 = (const u32 GCRE_CONSTANT*)a.lidx0;
-  const u64 GCRE_CONSTANT* doff = (const u64 GCRE_CONSTANT*)a.doff;
-  const u32 GCRE_CONSTANT* dlist = (const u32 GCRE_CONSTANT*)a.dlist;
-  const u32 GCRE_CONSTANT* tots = (const u32 GCRE_CONSTANT*)a.tot;
-  const u32 GCRE_CONSTANT* rowz = (const u32 GCRE_CONSTANT*)a.rowz;
-  const u32 GCRE_CONSTANT* ladder = (const u32 GCRE_CONSTANT*)a.ladder;
 
-  u32 nmax[32];
-#pragma unroll
-  for (int q = 0; q < 32; q++) nmax[q] = 0u;
   int cur_kt = -1;
   u32 valid = 0u;       // bit q: permutation 32*lane + q of the tile exists (< K)
-  u32 theta = 0u;       // wave-uniform: no running maximum of the tile is below this (f32 bit pattern)
   u32 lad_base = 0u;    // ladder row of the threshold level in use
+  bool dirty = false;   // the strip holds maxima the global array has not seen
+  u32 n_slow = 0u;      // statistics: joined-path tiles that reached the table lookup
   __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)a.mt, 0, 0x7fffffff, 0x00020000);
 
-  // push the wave's maxima to the global array, pull what the other waves found, and set the pruning threshold to
-  // the smallest running maximum of the tile's live permutations (stale reads only make it smaller: still exact)
+  // publish the wave's maxima, read everybody's, and set the pruning threshold to the smallest running maximum of
+  // the tile's live permutations (a stale read only lowers it: still exact)
   auto exchange = [&]() {
     u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
     u32 lo = 0xffffffffu;
-#pragma unroll
+#pragma unroll 8
     for (int q = 0; q < 32; q++) {
       const u32 g = __hip_atomic_load(out + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past the L1
-      if (nmax[q] > g) atomicMax(out + q, nmax[q]);
-      const u32 v = nmax[q] > g ? nmax[q] : g;
+      u32 v = g;
+      if (dirty) {
+        const u32 own = scr[q * 64];
+        if (own > g) {
+          atomicMax(out + q, own);
+          v = own;
+        }
+      }
       if ((valid >> q) & 1u) lo = v < lo ? v : lo;
     }
-    theta = __builtin_amdgcn_readfirstlane(wave_min_u32(lo));
+    dirty = false;
+    u32 theta = __builtin_amdgcn_readfirstlane(wave_min_u32(lo));
     if (theta == 0xffffffffu) theta = 0u;
-    // level j covers thresholds >= j / kLadderPerUnit
-    const float tf = __uint_as_float(theta);
-    int j = (int)(tf * (float)kLadderPerUnit);
+    int j = (int)(__uint_as_float(theta) * (float)kLadderPerUnit);   // level j covers thresholds >= j / kLadderPerUnit
     j = j < 0 ? 0 : (j > kLadderLevels - 1 ? kLadderLevels - 1 : j);
     lad_base = (u32)j * (u32)a.ladder_stride;
   };
   auto flush = [&]() {
     if (cur_kt < 0) return;
     u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
-#pragma unroll
     for (int q = 0; q < 32; q++) {
-      if (nmax[q] != 0u) atomicMax(out + q, nmax[q]);
-      nmax[q] = 0u;
+      const u32 own = scr[q * 64];
+      if (own != 0u) {
+        atomicMax(out + q, own);
+        scr[q * 64] = 0u;
+      }
     }
+    dirty = false;
   };
 
   auto to_counts = [&](const u32 (&C)[L], u32 (&R)[16]) {
@@ -110,10 +113,8 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
     for (int l = 0; l < 16; l++) R[l] = (l < L) ? C[l] : 0u;
     transpose16(R);
   };
-  auto wave_lds_fence = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  auto raise = [&](int q, u32 v) {
+    if (v > scr[q * 64]) scr[q * 64] = v;
   };
 
   // method 1: counts -> f32 table diagonal -> running maxima (methods.h:96-103)
@@ -121,25 +122,11 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
     u32 R[16];
     to_counts(C, R);
     const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(total);
-    if (total < (u32)kIeDiagCap) {
-      for (u32 i = (u32)lane; i <= total; i += 64) dl[i] = diag_g[i];
-      wave_lds_fence();
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const u32 lo = dl[R[j] & 0xffffu];
-        const u32 hi = dl[R[j] >> 16];
-        nmax[j] = (lo > nmax[j]) ? lo : nmax[j];
-        nmax[j + 16] = (hi > nmax[j + 16]) ? hi : nmax[j + 16];
-      }
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      for (int j = 0; j < 16; j++) {
-        const u32 lo = diag_g[R[j] & 0xffffu];
-        const u32 hi = diag_g[R[j] >> 16];
-        nmax[j] = (lo > nmax[j]) ? lo : nmax[j];
-        nmax[j + 16] = (hi > nmax[j + 16]) ? hi : nmax[j + 16];
-      }
+    for (int j = 0; j < 16; j++) {
+      raise(j, diag_g[R[j] & 0xffffu]);
+      raise(j + 16, diag_g[R[j] >> 16]);
     }
+    dirty = true;
   };
 
   // method 2: vtmax[a][tp-a] + vtmax[tn-b][b] in f64, rounded to f32, clamped at 0 (methods.h:220-230)
@@ -149,46 +136,51 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
     to_counts(Cn, Rn);
     const double* dp = a.d64 + sp_diag_offset(tp);
     const double* dn = a.d64 + sp_diag_offset(tn);
-    const bool staged = (tp < (u32)kIeDiagCap2 / 2) && (tn < (u32)kIeDiagCap2 / 2);
-    double* lp = (double*)dl;
-    double* ln = lp + kIeDiagCap2 / 2;
-    if (staged) {
-      for (u32 i = (u32)lane; i <= tp; i += 64) lp[i] = dp[i];
-      for (u32 i = (u32)lane; i <= tn; i += 64) ln[i] = dn[i];
-      wave_lds_fence();
-    }
-    auto one = [&](u32 ca, u32 cb, u32& m) {
-      const double s = staged ? (lp[ca] + ln[cb]) : (dp[ca] + dn[cb]);
-      float f = (float)s;
+    auto one = [&](u32 ca, u32 cb, int q) {
+      float f = (float)(dp[ca] + dn[cb]);
       f = (f > 0.0f) ? f : 0.0f;
-      const u32 v = __float_as_uint(f);
-      m = (v > m) ? v : m;
+      raise(q, __float_as_uint(f));
     };
-#pragma unroll
     for (int j = 0; j < 16; j++) {
-      one(Rp[j] & 0xffffu, Rn[j] & 0xffffu, nmax[j]);
-      one(Rp[j] >> 16, Rn[j] >> 16, nmax[j + 16]);
+      one(Rp[j] & 0xffffu, Rn[j] & 0xffffu, j);
+      one(Rp[j] >> 16, Rn[j] >> 16, j + 16);
     }
-    if (staged) __builtin_amdgcn_wave_barrier();
+    dirty = true;
   };
 
-  // some live permutation has a count outside [lo, hi]?  Two borrow chains over the planes, scalar bound bits:
-  // C < lo  <=>  C - lo borrows;  C > hi  <=>  hi - C borrows.
-  auto outside = [&](const u32 (&C)[L], u32 lo, u32 hi) -> bool {
+  // Per lane the live permutations whose count lies outside [lo, hi].  Two borrow chains over the planes, scalar
+  // bound bits:  C < lo  <=>  C - lo borrows;  C > hi  <=>  hi - C borrows.
+  auto outside = [&](const u32 (&C)[L], u32 lo, u32 hi) -> u32 {
     u32 blo = 0u, bhi = 0u;
 #pragma unroll
     for (int l = 0; l < L; l++) {
-      const u32 kl = (u32)(-(int)((lo >> l) & 1u));   // scalar: all ones when the bound has bit l
-      const u32 kh = (u32)(-(int)((hi >> l) & 1u));
+      const u32 kl = (u32)__builtin_amdgcn_sbfe((int)lo, l, 1);   // scalar: all ones when the bound has bit l
+      const u32 kh = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
       blo = maj3(~C[l], kl, blo);
       bhi = maj3(~kh, C[l], bhi);
     }
-    return __builtin_amdgcn_ballot_w64(((blo | bhi) & valid) != 0u) != 0ull;
+    return (blo | bhi) & valid;
   };
 
-  // count planes of one (row-half, tile): groups of 4 planes, [group][lane][4] dwords
-  auto load_planes = [&](u32 (&P)[L], const u32* planes, u64 rowhalf, int groups) {
-    const u32x4* src = (const u32x4*)(planes + ((rowhalf * (u64)a.nkt + (u64)cur_kt) * (u64)groups) * 256u) + lane;
+  // method 1, the few permutations that passed the test: rebuild each one's count from the planes, look it up
+  auto finish_some = [&](const u32 (&C)[L], u32 total, u32 m) {
+    const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(total);
+    while (m != 0u) {
+      const u32 b = (u32)__builtin_ctz(m);
+      m &= m - 1u;
+      u32 cnt = 0u;
+#pragma unroll
+      for (int l = 0; l < L; l++) cnt |= ((C[l] >> b) & 1u) << l;
+      const u32 v = diag_g[cnt];
+      if (v > scr[b * 64]) scr[b * 64] = v;
+    }
+    dirty = true;
+  };
+
+  // count planes of one (row-half, tile): `unit` = ((row*M + half) * nkt + tile) * groups; groups of 4 planes,
+  // [group][lane][4] dwords = 1 KB per group
+  auto load_planes = [&](u32 (&P)[L], const u32* planes, u32 unit, int groups) {
+    const u32x4* src = (const u32x4*)(planes + (u64)unit * 256u) + lane;
 #pragma unroll
     for (int j = 0; j < L / 4; j++) {
       u32x4 v = {0u, 0u, 0u, 0u};
@@ -210,31 +202,66 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
       mt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mt + (size_t)kt * a.mt_rows * 64), 0, 0x7fffffff, 0x00020000);
       const int live = a.K - kt * 2048 - lane * 32;           // permutations of this lane that exist
       valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
-      theta = 0u;
       lad_base = 0u;
     }
-    int since = kIeRefresh;   // refresh right away: pick up what earlier waves already published
+    // thresholds: refresh after 1, 2, 4, .. segments while they are still climbing, then every kIeRefresh
+    int since = 0, period = 1;
     for (i64 sidx = sl; sidx < a.nsegs; sidx += slices) {
       const u32 row0 = segs[sidx].row0;
       const u32 first = segs[sidx].first;
       const u32 npaths = segs[sidx].n;
-      if (a.prune && ++since > kIeRefresh) {
+      if (a.prune && !(a.ablate & 8) && ++since >= period) {
         exchange();
         since = 0;
+        period = period < kIeRefresh ? period * 2 : kIeRefresh;
       }
 
-      u32 x[16];
+      // ---- per-path metadata of the whole segment in a few coalesced loads: lane t <-> joined path first + t.
+      // The path loop below takes everything out of these registers with v_readlane.
+      const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
+      u64 ov64[M + 1];
+#pragma unroll
+      for (int h = 0; h <= M; h++) ov64[h] = a.doff[(u64)qv * M + h];
+      const u64 base0 = (((u64)(u32)__builtin_amdgcn_readfirstlane((int)(ov64[0] >> 32))) << 32 |
+                         (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)ov64[0])) & ~(u64)3;
+      u32 relv[M + 1];   // list begin relative to the segment's first list (entries), mode in bit 0
+#pragma unroll
+      for (int h = 0; h <= M; h++) relv[h] = (u32)(ov64[h] - base0);
+      const u32 rzv = a.rowz[qv];
+      u32 zunit[M];      // where the planes of the added row-half start, in 1 KB units
+#pragma unroll
+      for (int h = 0; h < M; h++) {
+        const u32 hz = (M == 2 && (rzv >> 31)) ? (u32)(1 - h) : (u32)h;
+        zunit[h] = ((u32)kt * (u32)a.rowsz + (rzv & 0x7fffffffu) * (u32)M + hz) * (u32)a.gz;
+      }
+      u32 ttv[M];
+#pragma unroll
+      for (int h = 0; h < M; h++) ttv[h] = a.tot[(u64)qv * M + h];
+      u32 lhv = 0u;
+      if constexpr (M == 1)
+        if (a.prune) lhv = a.ladder[lad_base + ttv[0]];
+      const u32* seg_list = a.dlist + base0;
+      u32 lv[M][8];      // the first 8 entries of every list (lists are padded to 8: most lists end there)
+#pragma unroll
+      for (int h = 0; h < M; h++) {
+        const u32x4* lp = (const u32x4*)(seg_list + (relv[h] & ~3u));
+        const u32x4 e0 = lp[0], e1 = lp[1];
+        lv[h][0] = e0.x; lv[h][1] = e0.y; lv[h][2] = e0.z; lv[h][3] = e0.w;
+        lv[h][4] = e1.x; lv[h][5] = e1.y; lv[h][6] = e1.z; lv[h][7] = e1.w;
+      }
+
       auto stream = [&](u32 (&P)[L], const u32 GCRE_CONSTANT* list, u64 p, u64 e) {
+        u32 x[16];
         for (; p + 16 <= e; p += 16) {
           load16(x, mt, lane4, *(const u32x16 GCRE_CONSTANT*)(list + p));
           add16<L>(P, x);
         }
         for (; p < e; p += 4) {
           const u32x4 offs = *(const u32x4 GCRE_CONSTANT*)(list + p);
-          u32 y[4];
+          u32 y4[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) y[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
-          add4<L>(P, y);
+          for (int j = 0; j < 4; j++) y4[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+          add4<L>(P, y4);
         }
       };
 
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
       for (int h = 0; h < M; h++) {
         const u64 r = (u64)row0 * M + h;
         if (a.planes0) {
-          load_planes(B[h], a.planes0, r, a.g0);
+          load_planes(B[h], a.planes0, (u32)(((u64)kt * (u64)a.rows0 + r) * (u64)a.g0), a.g0);
         } else {
 #pragma unroll
           for (int l = 0; l < L; l++) B[h][l] = 0u;
@@ -254,33 +281,55 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
 
       for (u32 t = 0; t < npaths; t++) {
         const u32 q = first + t;
-        const u32 rz = rowz[q];
         u32 C[M][L];
 #pragma unroll
         for (int h = 0; h < M; h++) {
-          const u64 d = (u64)q * M + h;
-          const u64 o0 = doff[d], o1 = doff[d + 1];
-          const u64 lb = o0 & ~(u64)3, le = o1 & ~(u64)3;
-          if ((o0 & 1u) == 0u) {
-            // delta list: the bits the join adds on top of paths0
+          const u32 r0 = rdlane(relv[h], t);
+          const u32 r1 = rdlane(relv[h + 1], t);
+          const u32 lb = r0 & ~3u, le = r1 & ~3u;
+          const bool overlap = (r0 & 1u) != 0u;
+          // the 8 mask rows every list starts with (zero rows past its real end) ...
+          u32 offs[8], y[8];
 #pragma unroll
-            for (int l = 0; l < L; l++) C[h][l] = B[h][l];
-            stream(C[h], dlist, lb, le);
+          for (int j = 0; j < 8; j++) offs[j] = (a.ablate & 2) ? a.zoff : rdlane(lv[h][j], t);
+#pragma unroll
+          for (int j = 0; j < 8; j++) y[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+          // ... and the planes of the row the join adds, when the list is the overlap with paths0
+          u32 Z[L];
+          if (overlap && !(a.ablate & 1)) {
+            load_planes(Z, a.planesz, rdlane(zunit[h], t), a.gz);
           } else {
-            // overlap list: C = B + Nz - popc(p0 & z & mask)
-            u32 S[L], Z[L];
 #pragma unroll
-            for (int l = 0; l < L; l++) S[l] = 0u;
-            const int hz = (M == 2 && (rz >> 31)) ? 1 - h : h;
-            load_planes(Z, a.planesz, (u64)(rz & 0x7fffffffu) * M + hz, a.gz);
-            stream(S, dlist, lb, le);
+            for (int l = 0; l < L; l++) Z[l] = 0u;
+          }
+          // sum of the 8 rows: 4 planes
+          u32 c0, a0, c1, a1, c2, a2, d0, b0;
+          csa(c0, a0, y[0], y[1], y[2]);
+          csa(c1, a1, y[3], y[4], y[5]);
+          csa(c2, a2, a0, a1, y[6]);
+          const u32 s0 = a2 ^ y[7], c3 = a2 & y[7];
+          csa(d0, b0, c0, c1, c2);
+          const u32 s1 = b0 ^ c3, d1 = b0 & c3;
+          u32 S[L];
+          S[0] = s0; S[1] = s1; S[2] = d0 ^ d1; S[3] = d0 & d1;
+#pragma unroll
+          for (int l = 4; l < L; l++) S[l] = 0u;
+          if (le - lb > 8u) stream(S, (const u32 GCRE_CONSTANT*)seg_list, (u64)lb + 8, (u64)le);   // long list (rare)
+          if (overlap) {   // C = B + Nz - S
             u32 cy = 0u, bw = 0u;
 #pragma unroll
             for (int l = 0; l < L; l++) {
-              const u32 s1 = B[h][l] ^ Z[l] ^ cy;
+              const u32 s1_ = B[h][l] ^ Z[l] ^ cy;
               cy = maj3(B[h][l], Z[l], cy);
-              C[h][l] = s1 ^ S[l] ^ bw;
-              bw = maj3(~s1, S[l], bw);
+              C[h][l] = s1_ ^ S[l] ^ bw;
+              bw = maj3(~s1_, S[l], bw);
+            }
+          } else {         // C = B + S
+            u32 cy = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              C[h][l] = B[h][l] ^ S[l] ^ cy;
+              cy = maj3(B[h][l], S[l], cy);
             }
           }
         }
@@ -288,7 +337,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
 #pragma unroll
           for (int h = 0; h < M; h++) {
             const u64 rh = ((u64)a.out_first + q) * M + h;
-            u32x4* dst = (u32x4*)(a.planes_out + ((rh * (u64)a.nkt + (u64)cur_kt) * (u64)a.go) * 256u) + lane;
+            u32x4* dst = (u32x4*)(a.planes_out + (((u64)cur_kt * (u64)a.rows_out + rh) * (u64)a.go) * 256u) + lane;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               if (j < a.go) {
@@ -300,48 +349,419 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie(const IeArgs a) {
           }
         }
         if (q < a.score_begin || q >= a.score_end) continue;   // planes only: the path belongs to another shard
+        if (a.ablate & 4) {   // diagnostics: keep the counters alive, skip the epilogue
+          if (C[0][0] == 0x12345678u && C[0][L - 1] == 0x9abcdef0u) scr[0] = 1u;
+          continue;
+        }
         if constexpr (M == 1) {
-          const u32 total = tots[q];
           if (a.prune) {
-            const u32 lh = ladder[lad_base + total];
-            if (!outside(C[0], lh & 0xffffu, lh >> 16)) continue;
+            const u32 lh = rdlane(lhv, t);
+            const u32 m = outside(C[0], lh & 0xffffu, lh >> 16);
+            const u64 lanes = __builtin_amdgcn_ballot_w64(m != 0u);
+            if (lanes == 0ull) continue;
+            n_slow++;
+            // a handful of permutations: one by one; many (thresholds still low): transpose all 2048 counts
+            if (__builtin_popcountll(lanes) <= 8 && __builtin_amdgcn_ballot_w64((m & (m - 1u)) != 0u && ((m & (m - 1u)) & ((m & (m - 1u)) - 1u)) != 0u) == 0ull) {
+              finish_some(C[0], rdlane(ttv[0], t), m);
+              continue;
+            }
           }
-          finish_m1(C[0], total);
+          finish_m1(C[0], rdlane(ttv[0], t));
         } else {
-          finish_m2(C[0], C[M - 1], tots[2 * q], tots[2 * q + 1]);
+          finish_m2(C[0], C[M - 1], rdlane(ttv[0], t), rdlane(ttv[M - 1], t));
         }
       }
     }
   }
   flush();
+  if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
 }
 
-#define GCRE_IE_DISPATCH(EXPR)                             \
-  if (method == 1) {                                       \
-    if (planes <= 8) { EXPR(1, 8); }                       \
-    else if (planes <= 12) { EXPR(1, 12); }                \
-    else { EXPR(1, 16); }                                  \
-  } else {                                                 \
-    if (planes <= 8) { EXPR(2, 8); }                       \
-    else if (planes <= 12) { EXPR(2, 12); }                \
-    else { EXPR(2, 16); }                                  \
+// ------------------------------------------------------------------------------------------------
+// method 1, the hot kernel.  L counter planes (multiple of 4), GZ plane groups of the added rows, OUT = the joined
+// paths' planes are written out (kept joins).  Both operands have planes; lists are padded to 8 entries.
+// Per joined path and tile, in the common case: 12 v_readlane, 8 mask-row loads + GZ wide loads, 14 bit ops for the
+// 8-row sum, ~3.3 per plane for B + (Nz - S), 2 per plane for the interval test -- every one a single v_bitop3.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ u32 majority(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+// borrow out of a - b - c (bitwise full subtractor): majority(~a, b, c)
+__device__ __forceinline__ u32 borrow3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x8E); }
+
+// sum of 8 one-bit rows -> 4 planes (14 ops)
+__device__ __forceinline__ void sum8(const u32 (&r)[8], u32 (&s)[4]) {
+  const u32 a0 = xor3(r[0], r[1], r[2]), c0 = majority(r[0], r[1], r[2]);
+  const u32 a1 = xor3(r[3], r[4], r[5]), c1 = majority(r[3], r[4], r[5]);
+  const u32 a2 = xor3(a0, a1, r[6]), c2 = majority(a0, a1, r[6]);
+  s[0] = a2 ^ r[7];
+  const u32 c3 = a2 & r[7];
+  const u32 b0 = xor3(c0, c1, c2), d0 = majority(c0, c1, c2);
+  s[1] = b0 ^ c3;
+  const u32 d1 = b0 & c3;
+  s[2] = d0 ^ d1;
+  s[3] = d0 & d1;
+}
+
+template <int L, int GZ, bool OUT>
+__global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
+  static_assert(L % 4 == 0 && L >= 8 && L <= 16 && GZ >= 2 && GZ <= L / 4, "planes come in groups of 4");
+  // the waves' running maxima: [q][lane] per wave; touched only by the few lookups that survive the interval test
+  __shared__ u32 nmax_lds[kIeWaves][32 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7;
+  const i64 wi = (i64)(blockIdx.x >> 3) * kIeWaves + wave;
+  const i64 wx = a.waves_per_xcd;
+  const i64 slices = 8 * wx;
+  const u32 lane4 = (u32)lane * 4u;
+  u32* nm = nmax_lds[wave] + lane;
+#pragma unroll
+  for (int q = 0; q < 32; q++) nm[q * 64] = 0u;
+  const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
+
+  int cur_kt = -1;
+  u32 valid = 0u;
+  u32 lad_base = (a.lad_mode == 0) ? 0u : (u32)(kLadderLevels - 1 + a.lad_mode) * (u32)a.ladder_stride;
+  bool dirty = false;     // nm holds maxima the global array has not seen
+  u32 n_slow = 0u;
+#ifdef GCRE_IE_TIMING
+  u64 tm[6] = {0, 0, 0, 0, 0, 0};   // seg prologue, load wait, compute, lookups, exchange, total
+  const u64 tm_begin = __builtin_amdgcn_s_memtime();
+#define GCRE_TM_MARK(var) __builtin_amdgcn_s_waitcnt(0); const u64 var = __builtin_amdgcn_s_memtime()
+#define GCRE_TM_ADD(i, t1, t0) tm[i] += (t1) - (t0)
+#else
+#define GCRE_TM_MARK(var)
+#define GCRE_TM_ADD(i, t1, t0)
+#endif
+  __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)a.mt, 0, 0x7fffffff, 0x00020000);
+
+  // publish the wave's maxima, read everybody's, set the threshold level to the smallest running maximum of the
+  // tile's live permutations (a stale read only lowers it: still exact)
+  auto exchange = [&]() {
+    // the tile's 2048 running maxima: lane holds 32 consecutive ones = 8 wide loads, issued together.  sc1: served
+    // by the memory side, not by this CU's L1 or this XCD's L2, which never see the other XCDs' atomics.
+    u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
+    __amdgpu_buffer_rsrc_t nb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.null_bits + (size_t)cur_kt * 2048), 0, 8192, 0x00020000);
+    u32x4 g4[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) g4[j] = __builtin_amdgcn_raw_buffer_load_b128(nb, (u32)lane * 128u + (u32)j * 16u, 0, 16 /* sc1 */);
+    u32 lo = 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      const u32 g = g4[q >> 2][q & 3];
+      const u32 own = nm[q * 64];
+      if (dirty && own > g) atomicMax(out + q, own);
+      const u32 v = own > g ? own : g;
+      if ((valid >> q) & 1u) lo = v < lo ? v : lo;
+    }
+    dirty = false;
+    u32 theta = __builtin_amdgcn_readfirstlane(wave_min_u32(lo));
+    if (theta == 0xffffffffu) theta = 0u;
+    int j = (int)(__uint_as_float(theta) * (float)kLadderPerUnit);   // level j covers thresholds >= j / kLadderPerUnit
+    j = j < 0 ? 0 : (j > kLadderLevels - 1 ? kLadderLevels - 1 : j);
+    lad_base = (u32)j * (u32)a.ladder_stride;
+  };
+  auto flush_tile = [&]() {
+    if (cur_kt >= 0) {
+      u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
+#pragma unroll 8
+      for (int q = 0; q < 32; q++) {
+        const u32 own = nm[q * 64];
+        if (own != 0u) {
+          atomicMax(out + q, own);
+          nm[q * 64] = 0u;
+        }
+      }
+    }
+    dirty = false;
+  };
+
+  for (int step = 0; step < a.nkt; step++) {
+    const i64 item = (i64)xcd * a.nkt * wx + wi + (i64)step * wx;
+    const int kt = (int)(item / slices);
+    const i64 sl = item % slices;
+    if (sl >= a.nsegs) continue;   // nothing for this wave in this tile
+    if (kt != cur_kt) {
+      flush_tile();
+      cur_kt = kt;
+      mt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mt + (size_t)kt * a.mt_rows * 64), 0, 0x7fffffff, 0x00020000);
+      const int live = a.K - kt * 2048 - lane * 32;
+      valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
+      if (a.lad_mode == 0) lad_base = 0u;
+    }
+    int since = 0, period = 1;   // thresholds: refresh after 1, 2, 4, .. segments while they climb, then every kIeRefresh
+    for (i64 sidx = sl; sidx < a.nsegs; sidx += slices) {
+      const u32 row0 = segs[sidx].row0;
+      const u32 first = segs[sidx].first;
+      const u32 npaths = segs[sidx].n;
+      GCRE_TM_MARK(ts0);
+      if (a.lad_mode == 0 && ++since >= period) {
+        exchange();
+        since = 0;
+        period = period < kIeRefresh ? period * 2 : kIeRefresh;
+      }
+      GCRE_TM_MARK(ts1);
+      GCRE_TM_ADD(4, ts1, ts0);
+
+      // ---- per-path metadata of the whole segment in a few coalesced loads: lane t <-> joined path first + t ----
+      const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
+      const u64 o0 = a.doff[qv], o1 = a.doff[qv + 1];
+      const u64 base0 = (((u64)(u32)__builtin_amdgcn_readfirstlane((int)(o0 >> 32))) << 32 |
+                         (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)o0)) & ~(u64)3;
+      const u32 rel0 = (u32)(o0 - base0);            // list begin relative to the segment's first list, mode in bit 0
+      const u32 lenv = (u32)((o1 & ~(u64)3) - (o0 & ~(u64)3));
+      const u32 zunit = ((u32)kt * (u32)a.rowsz + (a.rowz[qv] & 0x7fffffffu)) * (u32)a.gz;   // 1 KB units into planesz
+      const u32 totv = a.tot[qv];
+      const u32 lhv = a.ladder[lad_base + totv];
+      const u32* seg_list = a.dlist + base0;
+      u32 lv[8];          // the first 8 entries of every list (lists are padded to 8: most lists end there)
+      {
+        const u32x4* lp = (const u32x4*)(seg_list + (rel0 & ~3u));
+        const u32x4 e0 = lp[0], e1 = lp[1];
+        lv[0] = e0.x; lv[1] = e0.y; lv[2] = e0.z; lv[3] = e0.w;
+        lv[4] = e1.x; lv[5] = e1.y; lv[6] = e1.z; lv[7] = e1.w;
+      }
+      // ---- base counters: the planes of paths0[row0] ----
+      u32 B[L];
+      {
+        const u32x4* src = (const u32x4*)(a.planes0 + (((u64)kt * (u64)a.rows0 + (u64)row0) * (u64)a.g0) * 256u) + lane;
+#pragma unroll
+        for (int j = 0; j < L / 4; j++) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (j < a.g0) v = src[j * 64];
+          B[4 * j + 0] = v.x; B[4 * j + 1] = v.y; B[4 * j + 2] = v.z; B[4 * j + 3] = v.w;
+        }
+      }
+
+      GCRE_TM_MARK(ts2);
+      GCRE_TM_ADD(0, ts2, ts1);
+      // ---- the joined paths of the segment, software-pipelined one path ahead: the 8 mask rows and the planes of
+      // path t+1 are in flight while path t is computed.  Loads are issued unconditionally (the last path is simply
+      // requested twice) so that the compiler's counters let the older loads retire without draining the younger.
+      auto issue = [&](u32 t2, u32 (&yy)[8], u32 (&ZZ)[4 * GZ]) {
+        u32 offs[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) offs[j] = rdlane(lv[j], t2);
+#pragma unroll
+        for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+        const u32x4* src = (const u32x4*)(a.planesz + (u64)rdlane(zunit, t2) * 256u) + lane;
+#pragma unroll
+        for (int j = 0; j < GZ; j++) {
+          const u32x4 v = src[j * 64];
+          ZZ[4 * j + 0] = v.x; ZZ[4 * j + 1] = v.y; ZZ[4 * j + 2] = v.z; ZZ[4 * j + 3] = v.w;
+        }
+      };
+      auto compute = [&](u32 t, const u32 (&y)[8], const u32 (&Z)[4 * GZ]) {
+        GCRE_TM_MARK(tp0);
+        const u32 r0 = rdlane(rel0, t);
+        const u32 len = rdlane(lenv, t);
+        const bool overlap = (r0 & 1u) != 0u;
+        u32 C[L];
+        u32 S4[4];
+        sum8(y, S4);
+        if (len <= 8u && overlap) {
+          // ---- C = B + (Nz - S): the common case.  Nz - S >= 0: the overlap is part of the added row ----
+          u32 T[4 * GZ];
+          u32 bw = 0u;
+#pragma unroll
+          for (int l = 0; l < 4 * GZ; l++) {
+            if (l < 4) {
+              T[l] = xor3(Z[l], S4[l < 4 ? l : 0], bw);
+              bw = borrow3(Z[l], S4[l < 4 ? l : 0], bw);
+            } else {
+              T[l] = Z[l] ^ bw;
+              bw = bw & ~Z[l];
+            }
+          }
+          u32 cy = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            if (l < 4 * GZ) {
+              C[l] = xor3(B[l], T[l < 4 * GZ ? l : 0], cy);
+              cy = majority(B[l], T[l < 4 * GZ ? l : 0], cy);
+            } else {
+              C[l] = B[l] ^ cy;
+              cy = B[l] & cy;
+            }
+          }
+        } else if (len <= 8u) {
+          // ---- C = B + S: the join adds at most 8 patients ----
+          u32 cy = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            if (l < 4) {
+              C[l] = xor3(B[l], S4[l < 4 ? l : 0], cy);
+              cy = majority(B[l], S4[l < 4 ? l : 0], cy);
+            } else {
+              C[l] = B[l] ^ cy;
+              cy = B[l] & cy;
+            }
+          }
+        } else {
+          // ---- long list (rare): further blocks of 8 entries, each summed and rippled into a full-width S ----
+          u32 S[L];
+#pragma unroll
+          for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
+          const u32 lb = r0 & ~3u;
+          for (u32 p = lb + 8u; p < lb + len; p += 8u) {
+            typedef u32 __attribute__((ext_vector_type(8))) u32x8;
+            const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)((const u32 GCRE_CONSTANT*)seg_list + p);
+            u32 yy[8], s4[4];
+#pragma unroll
+            for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o8[j], 0);
+            sum8(yy, s4);
+            u32 cy = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              const u32 sv = S[l];
+              if (l < 4) {
+                S[l] = xor3(sv, s4[l < 4 ? l : 0], cy);
+                cy = majority(sv, s4[l < 4 ? l : 0], cy);
+              } else {
+                S[l] = sv ^ cy;
+                cy = sv & cy;
+              }
+            }
+          }
+          if (overlap) {   // C = B + Nz - S
+            u32 cy = 0u, bw = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              const u32 zl = (l < 4 * GZ) ? Z[l < 4 * GZ ? l : 0] : 0u;
+              const u32 s1_ = xor3(B[l], zl, cy);
+              cy = majority(B[l], zl, cy);
+              C[l] = xor3(s1_, S[l], bw);
+              bw = borrow3(s1_, S[l], bw);
+            }
+          } else {         // C = B + S
+            u32 cy = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              C[l] = xor3(B[l], S[l], cy);
+              cy = majority(B[l], S[l], cy);
+            }
+          }
+        }
+        if constexpr (OUT) {
+          const u64 rh = (u64)a.out_first + first + t;
+          u32x4* dst = (u32x4*)(a.planes_out + (((u64)kt * (u64)a.rows_out + rh) * (u64)a.go) * 256u) + lane;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (j < a.go) {
+              u32x4 v = {0u, 0u, 0u, 0u};
+              if (4 * j < L) v = u32x4{C[(4 * j) % L], C[(4 * j + 1) % L], C[(4 * j + 2) % L], C[(4 * j + 3) % L]};
+              dst[j * 64] = v;
+            }
+          }
+        }
+        // ---- interval test: live permutations whose count lies outside [lo, hi] of the path's diagonal ----
+        const u32 lh = rdlane(lhv, t);
+        const u32 lo = lh & 0xffffu, hi = lh >> 16;
+        u32 blo = 0u, bhi = 0u;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          const u32 kl = (u32)__builtin_amdgcn_sbfe((int)lo, l, 1);   // scalar: all ones when the bound has bit l
+          const u32 kh = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
+          blo = borrow3(C[l], kl, blo);    // C - lo borrows  <=>  C < lo
+          bhi = borrow3(kh, C[l], bhi);    // hi - C borrows  <=>  C > hi
+        }
+        u32 m = (blo | bhi) & valid;
+        GCRE_TM_MARK(tp2);
+        GCRE_TM_ADD(2, tp2, tp0);
+        if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) return;
+        // ---- the few permutations that can raise a maximum: rebuild each count from the planes, look it up ----
+        n_slow++;
+        const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(rdlane(totv, t));
+        while (m != 0u) {
+          // up to 4 permutations per round: their table cells are independent loads in flight together
+          u32 bb[4], vv[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            bb[k] = m ? (u32)__builtin_ctz(m) : bb[k ? k - 1 : 0];   // exhausted: repeat the last one (max is idempotent)
+            m &= m - 1u;
+            u32 cnt = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) cnt |= ((C[l] >> bb[k]) & 1u) << l;
+            vv[k] = diag_g[cnt];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            __hip_atomic_fetch_max(nm + bb[k] * 64, vv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_max_u32
+        }
+        dirty = true;
+        GCRE_TM_MARK(tp3);
+        GCRE_TM_ADD(3, tp3, tp2);
+      };
+
+      u32 yA[8], yB[8], ZA[4 * GZ], ZB[4 * GZ];
+      const u32 last = npaths - 1u;
+      issue(0u, yA, ZA);
+      for (u32 t = 0; t < npaths; t += 2) {
+        issue(t + 1 < last ? t + 1 : last, yB, ZB);
+        compute(t, yA, ZA);
+        if (t + 1 < npaths) {
+          issue(t + 2 < last ? t + 2 : last, yA, ZA);
+          compute(t + 1, yB, ZB);
+        }
+      }
+    }
+  }
+  flush_tile();
+#ifdef GCRE_IE_TIMING
+  tm[5] = __builtin_amdgcn_s_memtime() - tm_begin;
+  if (a.timing && lane == 0)
+    for (int i = 0; i < 6; i++) atomicAdd((unsigned long long*)a.timing + i, (unsigned long long)tm[i]);
+#endif
+  if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
+}
+
+// method 2 runs the general kernel; method 1 the specialised one: L from the largest carrier total, GZ = plane groups of
+// the added rows that can be non-zero (<= L/4), OUT = planes of the joined paths wanted
+#define GCRE_IE_M2(EXPR)                    \
+  if (planes <= 8) { EXPR(2, 8); }          \
+  else if (planes <= 12) { EXPR(2, 12); }   \
+  else { EXPR(2, 16); }
+
+#define GCRE_IE_M1(EXPR)                                                     \
+  if (planes <= 8) { if (out) { EXPR(8, 2, true); } else { EXPR(8, 2, false); } }            \
+  else if (planes <= 12) {                                                   \
+    if (gz <= 2) { if (out) { EXPR(12, 2, true); } else { EXPR(12, 2, false); } }            \
+    else { if (out) { EXPR(12, 3, true); } else { EXPR(12, 3, false); } }                    \
+  } else {                                                                   \
+    if (gz <= 2) { if (out) { EXPR(16, 2, true); } else { EXPR(16, 2, false); } }            \
+    else if (gz == 3) { if (out) { EXPR(16, 3, true); } else { EXPR(16, 3, false); } }       \
+    else { if (out) { EXPR(16, 4, true); } else { EXPR(16, 4, false); } }                    \
   }
 
 hipError_t launch_null_ie(const IeArgs& a, int method, int planes, hipStream_t stream) {
   const dim3 grid((unsigned)(8 * a.waves_per_xcd / kIeWaves));
   const dim3 block(64 * kIeWaves);
-#define GCRE_LAUNCH(MM, LL) hipLaunchKernelGGL((k_null_ie<MM, LL>), grid, block, 0, stream, a)
-  GCRE_IE_DISPATCH(GCRE_LAUNCH)
+  if (method == 1) {
+    const int gz = a.gz;
+    const bool out = a.planes_out != nullptr;
+#define GCRE_LAUNCH(LL, GG, OO) hipLaunchKernelGGL((k_null_ie_m1<LL, GG, OO>), grid, block, 0, stream, a)
+    GCRE_IE_M1(GCRE_LAUNCH)
 #undef GCRE_LAUNCH
+  } else {
+#define GCRE_LAUNCH(MM, LL) hipLaunchKernelGGL((k_null_ie<MM, LL>), grid, block, 0, stream, a)
+    GCRE_IE_M2(GCRE_LAUNCH)
+#undef GCRE_LAUNCH
+  }
   return hipGetLastError();
 }
 
-int ie_max_waves_per_cu(int method, int planes) {
+int ie_max_waves_per_cu(int method, int planes, int gz, bool out) {
   int blocks = 0;
   hipError_t e = hipSuccess;
-#define GCRE_OCC(MM, LL) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie<MM, LL>, 64 * kIeWaves, 0)
-  GCRE_IE_DISPATCH(GCRE_OCC)
+  if (method == 1) {
+#define GCRE_OCC(LL, GG, OO) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m1<LL, GG, OO>, 64 * kIeWaves, 0)
+    GCRE_IE_M1(GCRE_OCC)
 #undef GCRE_OCC
+  } else {
+#define GCRE_OCC(MM, LL) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie<MM, LL>, 64 * kIeWaves, 0)
+    GCRE_IE_M2(GCRE_OCC)
+#undef GCRE_OCC
+  }
   if (e != hipSuccess || blocks < 1) blocks = 1;
   return blocks * kIeWaves;
 }
@@ -381,7 +801,7 @@ __global__ __launch_bounds__(256) void k_build_planes(const u32* mt_all, u32 mt_
       for (int j = 0; j < 4; j++) y[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
       add4<L>(P, y);
     }
-    u32x4* dst = (u32x4*)(planes + (((u64)rr * (u64)nkt + (u64)w) * (u64)groups) * 256u) + lane;
+    u32x4* dst = (u32x4*)(planes + (((u64)w * (u64)nrowhalves + (u64)rr) * (u64)groups) * 256u) + lane;
 #pragma unroll
     for (int j = 0; j < L / 4; j++)
       if (j < groups) dst[j * 64] = u32x4{P[4 * j], P[4 * j + 1], P[4 * j + 2], P[4 * j + 3]};
@@ -426,6 +846,10 @@ __global__ void k_build_ladder(const u32* t32, int TD, u32* ladder) {
       ladder[(size_t)j * TD + t] = 1u;   // lo = 1, hi = 0
     }
   }
+  // two constant rows behind the levels: "every count is inside" (nothing is looked up: planes-only launches) and
+  // "every count is outside" (everything is looked up: GCRE_IE_PRUNE=0)
+  ladder[(size_t)kLadderLevels * TD + t] = 0xffff0000u;
+  ladder[(size_t)(kLadderLevels + 1) * TD + t] = 1u;
 }
 
 hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipStream_t stream) {

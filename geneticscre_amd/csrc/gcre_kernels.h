@@ -96,28 +96,34 @@ struct IeArgs {
   const uint32_t* tot;       // carriers per joined path (and half) of the launch
   const uint32_t* rowz;      // per joined path: row of the reduced operand | swap << 31
   const SparseSeg* segs;
-  const uint32_t* planes0;   // count planes of paths0 [row*M+h][nkt][g0][64][4], or nullptr: stream loff0/lidx0
-  const uint32_t* planesz;   // count planes of the reduced operand [row*M+h][nkt][gz][64][4] (mode-1 paths)
+  const uint32_t* planes0;   // count planes of paths0 [tile][row*M+h][g0][64][4], or nullptr: stream loff0/lidx0
+  const uint32_t* planesz;   // count planes of the reduced operand [tile][row*M+h][gz][64][4] (mode-1 paths)
+  uint32_t rows0, rowsz, rows_out;   // row-halves (rows * M) of the three plane arrays
   const uint64_t* loff0;
   const uint32_t* lidx0;
-  const uint64_t* doff;      // [count*M+1] list offsets (multiples of 4); bit 0 = mode: 0 delta list, 1 overlap list
+  const uint64_t* doff;      // [count*M+1] list offsets (multiples of 8, every list >= 8 entries); bit 0 = mode: 0 delta list, 1 overlap list
   const uint32_t* dlist;
   const float* t32;
   const double* d64;
-  const uint32_t* ladder;    // [kLadderLevels][ladder_stride] hi << 16 | lo (method 1)
+  const uint32_t* ladder;    // [kLadderLevels + 2][ladder_stride] hi << 16 | lo (method 1); rows kLadderLevels, +1: all inside / all outside
   uint32_t* null_bits;
-  uint32_t* planes_out;      // optional: planes of the joined paths [(out_first+q)*M+h][nkt][go][64][4]
+  uint64_t* timing;          // diagnostics build (-DGCRE_IE_TIMING): 6 per-section cycle sums over all waves
+  uint32_t* stats;           // optional: [0] += joined-path tiles that were looked up (not pruned)
+  uint32_t* scratch;         // 2048 dwords per wave of the launch, zero on entry and on exit: the waves' running maxima
+  uint32_t* planes_out;      // optional: planes of the joined paths [tile][(out_first+q)*M+h][go][64][4]
   int64_t out_first;
   int64_t nsegs;
   uint32_t score_begin, score_end;   // joined paths of the launch outside [begin, end) only produce planes
   int nkt, waves_per_xcd, K;
   int g0, gz, go;            // plane groups (4 planes each) of the three plane arrays
-  int prune;                 // method 1: test counts against the ladder before the table lookup
+  int prune;                 // general kernel, method 1: test counts against the ladder before the table lookup
+  int lad_mode;              // method-1 kernel: 0 thresholds from the running maxima, 1 look nothing up, 2 look everything up
   int ladder_stride;         // = number of table diagonals
   uint32_t mt_rows, zoff;
+  int ablate;                // diagnostics only (GCRE_IE_ABLATE): wrong results, shows where the time goes
 };
 hipError_t launch_null_ie(const IeArgs& a, int method, int planes, hipStream_t stream);
-int ie_max_waves_per_cu(int method, int planes);
+int ie_max_waves_per_cu(int method, int planes, int gz, bool out);
 hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, const uint64_t* loff, const uint32_t* lidx,
                                int64_t nrowhalves, int groups, uint32_t* planes, hipStream_t stream);
 hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipStream_t stream);

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
           extra = wave_sum(extra);
           if (lane == 0) {
             const u32 mode = (a.ie_bias >= 0 && ov + (u32)a.ie_bias < dl) ? 1u : 0u;
-            a.dcnt[i] = (((mode ? ov : dl) + 3u) & ~3u) | mode;
+            a.dcnt[i] = max(8u, ((mode ? ov : dl) + 7u) & ~7u) | mode;   // the IE kernel always loads 8 entries
             a.rowz[i] = rz | zflip;
             // paths0 | reduced row must be the joined path: reduced row inside it, same number of carriers
             if (extra != 0u || px + dl != cs + ct) *a.bad = 1u;
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a) {
           if (lane == 0) {
             const u32 mp = (a.ie_bias >= 0 && ovp + (u32)a.ie_bias < dlp) ? 1u : 0u;
             const u32 mn = (a.ie_bias >= 0 && ovn + (u32)a.ie_bias < dln) ? 1u : 0u;
-            a.dcnt[2 * i] = (((mp ? ovp : dlp) + 3u) & ~3u) | mp;
-            a.dcnt[2 * i + 1] = (((mn ? ovn : dln) + 3u) & ~3u) | mn;
+            a.dcnt[2 * i] = max(8u, ((mp ? ovp : dlp) + 7u) & ~7u) | mp;
+            a.dcnt[2 * i + 1] = max(8u, ((mn ? ovn : dln) + 7u) & ~7u) | mn;
             a.rowz[i] = rz | zflip;
             if (extra != 0u || pxp + dlp != case_pos + ctrl_neg || pxn + dln != case_neg + ctrl_pos) *a.bad = 1u;
             wave_modes += mp + mn;

@@ -74,6 +74,9 @@ typedef struct {
   int64_t ie_overlap_lists;   /* joined-path halves scored as N0 + Nz - overlap (the rest streamed their delta list) */
   int64_t ie_hinted_joins;    /* joins that ran on a verified gcre_uids_set_reduced operand */
   int64_t ie_plane_joins;     /* joins whose paths0 count planes were already resident */
+  int64_t ie_lookup_tiles;    /* joined-path x 2048-permutation tiles that survived the pruning test (method 1) */
+  double prepare_ms;          /* host wall time: bit lists / count planes of the operands (once per set and mask epoch) */
+  double inspect_ms;          /* host wall time: list offsets (scan), list fill and the syncs around them */
 } gcre_profile;
 
 /* ---- context: JoinExec::JoinExec, src/join_base.cpp:37-59.  method 1 = unsigned, 2 = signed. ---- */
