@@ -81,7 +81,8 @@ struct gcre_ctx {
   double* d_dmax = nullptr;          // method 2 null table (vtmax)
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
-  uint32_t* d_max_tot = nullptr;     // 2 words: largest carrier total of the current chunk, "reduced operand is wrong" flag
+  uint32_t* d_max_tot = nullptr;     // 8 words: largest carrier total of the chunk, "reduced operand is wrong", overlap lists,
+                                     // looked-up tiles, entries reserved in the long-list area
   uint32_t* d_ladder = nullptr;      // method 1: pruning ladder of the null table [kLadderLevels][TD]
   int null_kernel = 0;               // 0 auto, 1 dense, 2 sparse, 3 ie (GCRE_NULL_KERNEL)
   int sparse_waves_per_cu = 32;
@@ -91,7 +92,7 @@ struct gcre_ctx {
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
   DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan;
-  DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz, d_ie_scratch;
+  DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz, d_ie_scratch, d_linfo, d_lover, d_dover;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
 
   gcre_profile prof{};
@@ -678,20 +679,35 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         const bool use_sparse = sg.score && sparse_ok && !want_ie;
         if (use_sparse || use_ie) {
           collect_ie_stat();
-          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 16, st));
+          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 32, st));
           sa.max_tot = c->d_max_tot;
           HIP_TRY(c, c->d_dcnt.reserve((size_t)n * g.method));
           sa.dcnt = c->d_dcnt.p;
         }
         if (use_ie) {
+          // one pass: statistics, kept rows, the check of the reduced operand, and the lists the null kernel streams
+          const size_t nl = (size_t)n * g.method;
           HIP_TRY(c, c->d_rowz.reserve(cap));
+          HIP_TRY(c, c->d_linfo.reserve(nl));
+          HIP_TRY(c, c->d_lover.reserve(nl));
+          HIP_TRY(c, c->d_dlist.reserve(nl * 8 + 16));
+          HIP_TRY(c, c->d_dover.reserve(std::max<size_t>(c->d_dover.cap, nl * 2 + 64)));
           sa.pz = red->d_rows;
           sa.zindex = hinted ? u.d_red_index : nullptr;
           sa.rowz = c->d_rowz.p;
           sa.bad = c->d_max_tot + 1;
           sa.ie_bias = 8;
+          sa.linfo = c->d_linfo.p;
+          sa.lover = c->d_lover.p;
+          sa.slot = c->d_dlist.p;
+          sa.over = c->d_dover.p;
+          sa.over_cap = (uint32_t)std::min<size_t>(c->d_dover.cap - 16, 0xfffffff0u);
+          sa.ov_count = c->d_max_tot + 4;
+          sa.zoff = (uint32_t)(64 * g.Wp) << 8;
+          HIP_TRY(c, launch_stats_ie(sa, g.method, st));
+        } else {
+          HIP_TRY(c, launch_stats(sa, g.method, st));
         }
-        HIP_TRY(c, launch_stats(sa, g.method, st));
         HIP_TRY(c, hipEventRecord(e1, st));
         c->ev_stats.emplace_back(e0, e1);
         if (!sg.score && !(use_ie && g.K > 0)) continue;
@@ -701,14 +717,16 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           const auto ti0 = std::chrono::steady_clock::now();
           const uint32_t zoff = (uint32_t)(64 * g.Wp) << 8;
           const int64_t nl = n * g.method;
-          HIP_TRY(c, c->d_doff.reserve((size_t)nl + 1));
-          HIP_TRY(c, c->d_scan.reserve((size_t)(nl + 1023) / 1024 + 2));
-          HIP_TRY(c, launch_scan_u32_u64(c->d_dcnt.p, nl, c->d_doff.p, c->d_scan.p, st));
-          uint32_t flags[4] = {0, 0, 0, 0};   // max carriers, hint broken, overlap-mode lists
-          uint64_t n_list = 0;
-          HIP_TRY(c, hipMemcpyAsync(flags, c->d_max_tot, 16, hipMemcpyDeviceToHost, st));
-          HIP_TRY(c, hipMemcpyAsync(&n_list, c->d_doff.p + nl, 8, hipMemcpyDeviceToHost, st));
+          uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // max carriers, hint broken, overlap lists, -, long-list entries
+          HIP_TRY(c, hipMemcpyAsync(flags, c->d_max_tot, 32, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipStreamSynchronize(st));
+          if ((size_t)flags[4] + 16 > c->d_dover.cap) {
+            // more long lists than the area holds: size it from what the pass asked for, run the chunk again
+            HIP_TRY(c, c->d_dover.reserve((size_t)flags[4] + (size_t)flags[4] / 4 + 64));
+            redo = true;
+            break;
+          }
+          const uint64_t n_list = (uint64_t)nl * 8 + flags[4];
           const uint32_t max_tot = flags[0];
           join_max_tot = std::max(join_max_tot, max_tot);
           if (flags[1] != 0) {
@@ -729,9 +747,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             const double dense_cost = 2.0 * g.Wp * g.method * (double)g.K * 2.0 / 65.0;
             if (ie_cost >= dense_cost) { res_planes_ok = false; break; }
           }
-          HIP_TRY(c, c->d_dlist.reserve((size_t)n_list + 16));
-          HIP_TRY(c, launch_ie_fill((const uint32_t*)jp.p0->d_rows, 2 * g.S, 2 * g.Wp, g.method, c->d_row0.p, c->d_rowz.p, n,
-                                    red->d_loff, red->d_lidx, c->d_doff.p, zoff, c->d_dlist.p, st));
           int planes = 5;
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           IeArgs ia{};
@@ -748,8 +763,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.rows_out = res_planes ? (uint32_t)(jp.res->nrows * g.method) : 0u;
           ia.loff0 = jp.p0->d_loff;
           ia.lidx0 = jp.p0->d_lidx;
-          ia.doff = c->d_doff.p;
+          ia.linfo = c->d_linfo.p;
+          ia.lover = c->d_lover.p;
           ia.dlist = c->d_dlist.p;
+          ia.dover = c->d_dover.p;
           ia.t32 = c->d_t32;
           ia.d64 = c->d_dmax;
           ia.ladder = c->d_ladder;
@@ -775,6 +792,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
           const int wpc = std::min(c->sparse_waves_per_cu, ie_max_waves_per_cu(g.method, planes, ia.gz, ia.planes_out != nullptr));
           ia.waves_per_xcd = std::max(4, (dev_cus * wpc / 8 / 4) * 4);
+          // small joins: a wave's fixed costs (cold TLB and caches, LDS set-up, threshold exchange) are per tile, so give
+          // every wave at least ~32 joined paths per tile
+          while (ia.waves_per_xcd > 4 && n < (int64_t)8 * ia.waves_per_xcd * 32)
+            ia.waves_per_xcd = std::max(4, (ia.waves_per_xcd / 2 / 4) * 4);
           c->prof.inspect_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
           {
             // running maxima of the waves: 8 KB each, zero between launches (the kernel leaves them zero)
@@ -1081,7 +1102,7 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
 
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_case_mask, (size_t)g.Wp * 8) == hipSuccess;
-  ok = ok && hipMalloc((void**)&c->d_max_tot, 16) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_max_tot, 32) == hipSuccess;
   if (ok && g.Kpad > 0) {
     ok = hipMalloc((void**)&c->d_masks, (size_t)2 * g.Wp * g.Kpad * 4) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_null, (size_t)g.Kpad * 4) == hipSuccess;
@@ -1119,6 +1140,9 @@ void gcre_destroy(gcre_ctx* c) {
   c->d_dlist.release();
   c->d_rowz.release();
   c->d_ie_scratch.release();
+  c->d_linfo.release();
+  c->d_lover.release();
+  c->d_dover.release();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -219,14 +219,12 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
       // ---- per-path metadata of the whole segment in a few coalesced loads: lane t <-> joined path first + t.
       // The path loop below takes everything out of these registers with v_readlane.
       const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
-      u64 ov64[M + 1];
+      u32 infov[M], lovv[M];   // padded list length | mode, and where a long list continues
 #pragma unroll
-      for (int h = 0; h <= M; h++) ov64[h] = a.doff[(u64)qv * M + h];
-      const u64 base0 = (((u64)(u32)__builtin_amdgcn_readfirstlane((int)(ov64[0] >> 32))) << 32 |
-                         (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)ov64[0])) & ~(u64)3;
-      u32 relv[M + 1];   // list begin relative to the segment's first list (entries), mode in bit 0
-#pragma unroll
-      for (int h = 0; h <= M; h++) relv[h] = (u32)(ov64[h] - base0);
+      for (int h = 0; h < M; h++) {
+        infov[h] = a.linfo[(u64)qv * M + h];
+        lovv[h] = a.lover[(u64)qv * M + h];
+      }
       const u32 rzv = a.rowz[qv];
       u32 zunit[M];      // where the planes of the added row-half start, in 1 KB units
 #pragma unroll
@@ -240,11 +238,10 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
       u32 lhv = 0u;
       if constexpr (M == 1)
         if (a.prune) lhv = a.ladder[lad_base + ttv[0]];
-      const u32* seg_list = a.dlist + base0;
       u32 lv[M][8];      // the first 8 entries of every list (lists are padded to 8: most lists end there)
 #pragma unroll
       for (int h = 0; h < M; h++) {
-        const u32x4* lp = (const u32x4*)(seg_list + (relv[h] & ~3u));
+        const u32x4* lp = (const u32x4*)(a.dlist + ((u64)qv * M + h) * 8u);
         const u32x4 e0 = lp[0], e1 = lp[1];
         lv[h][0] = e0.x; lv[h][1] = e0.y; lv[h][2] = e0.z; lv[h][3] = e0.w;
         lv[h][4] = e1.x; lv[h][5] = e1.y; lv[h][6] = e1.z; lv[h][7] = e1.w;
@@ -284,9 +281,8 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
         u32 C[M][L];
 #pragma unroll
         for (int h = 0; h < M; h++) {
-          const u32 r0 = rdlane(relv[h], t);
-          const u32 r1 = rdlane(relv[h + 1], t);
-          const u32 lb = r0 & ~3u, le = r1 & ~3u;
+          const u32 r0 = rdlane(infov[h], t);
+          const u32 len = r0 & ~7u;
           const bool overlap = (r0 & 1u) != 0u;
           // the 8 mask rows every list starts with (zero rows past its real end) ...
           u32 offs[8], y[8];
@@ -314,7 +310,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
           S[0] = s0; S[1] = s1; S[2] = d0 ^ d1; S[3] = d0 & d1;
 #pragma unroll
           for (int l = 4; l < L; l++) S[l] = 0u;
-          if (le - lb > 8u) stream(S, (const u32 GCRE_CONSTANT*)seg_list, (u64)lb + 8, (u64)le);   // long list (rare)
+          if (len > 8u) stream(S, (const u32 GCRE_CONSTANT*)(a.dover + rdlane(lovv[h], t)), 0, (u64)(len - 8u));   // long list (rare)
           if (overlap) {   // C = B + Nz - S
             u32 cy = 0u, bw = 0u;
 #pragma unroll
@@ -505,18 +501,14 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
 
       // ---- per-path metadata of the whole segment in a few coalesced loads: lane t <-> joined path first + t ----
       const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
-      const u64 o0 = a.doff[qv], o1 = a.doff[qv + 1];
-      const u64 base0 = (((u64)(u32)__builtin_amdgcn_readfirstlane((int)(o0 >> 32))) << 32 |
-                         (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)o0)) & ~(u64)3;
-      const u32 rel0 = (u32)(o0 - base0);            // list begin relative to the segment's first list, mode in bit 0
-      const u32 lenv = (u32)((o1 & ~(u64)3) - (o0 & ~(u64)3));
+      const u32 infov = a.linfo[qv];                 // padded list length | mode
+      const u32 lovv = a.lover[qv];                  // where a long list continues
       const u32 zunit = ((u32)kt * (u32)a.rowsz + (a.rowz[qv] & 0x7fffffffu)) * (u32)a.gz;   // 1 KB units into planesz
       const u32 totv = a.tot[qv];
       const u32 lhv = a.ladder[lad_base + totv];
-      const u32* seg_list = a.dlist + base0;
       u32 lv[8];          // the first 8 entries of every list (lists are padded to 8: most lists end there)
       {
-        const u32x4* lp = (const u32x4*)(seg_list + (rel0 & ~3u));
+        const u32x4* lp = (const u32x4*)(a.dlist + (u64)qv * 8u);
         const u32x4 e0 = lp[0], e1 = lp[1];
         lv[0] = e0.x; lv[1] = e0.y; lv[2] = e0.z; lv[3] = e0.w;
         lv[4] = e1.x; lv[5] = e1.y; lv[6] = e1.z; lv[7] = e1.w;
@@ -553,8 +545,8 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       };
       auto compute = [&](u32 t, const u32 (&y)[8], const u32 (&Z)[4 * GZ]) {
         GCRE_TM_MARK(tp0);
-        const u32 r0 = rdlane(rel0, t);
-        const u32 len = rdlane(lenv, t);
+        const u32 r0 = rdlane(infov, t);
+        const u32 len = r0 & ~7u;
         const bool overlap = (r0 & 1u) != 0u;
         u32 C[L];
         u32 S4[4];
@@ -602,10 +594,10 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
           u32 S[L];
 #pragma unroll
           for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
-          const u32 lb = r0 & ~3u;
-          for (u32 p = lb + 8u; p < lb + len; p += 8u) {
+          const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + rdlane(lovv, t));
+          for (u32 p = 0u; p + 8u < len; p += 8u) {
             typedef u32 __attribute__((ext_vector_type(8))) u32x8;
-            const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)((const u32 GCRE_CONSTANT*)seg_list + p);
+            const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
             u32 yy[8], s4[4];
 #pragma unroll
             for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o8[j], 0);
@@ -902,6 +894,224 @@ hipError_t launch_ie_fill(const uint32_t* p0, int S32, int W32p, int method, con
   const i64 blocks = (count * method + 3) / 4;
   hipLaunchKernelGGL(k_ie_fill, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream, p0, S32, W32p,
                      method, row0, rowz, count, loffz, lidxz, doff, zoff, dlist);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// inspector of the IE form, one pass: real-label statistics and observed score of every joined path (what k_stats
+// does, methods.h:73-93), the kept row, the check of the reduced operand, the choice delta / overlap list and the
+// list itself.  One wave per joined path.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 ie_score_key(double s) {
+  // order-preserving image of a double; 0 = "not a candidate" (score not > -inf, or NaN: methods.h:91)
+  if (!(s > -__builtin_inf())) return 0;
+  const u64 b = (u64)__double_as_longlong(s);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// inclusive prefix sum inside every row of 16 lanes (DPP row_shr: no LDS); lane 15 of a row ends up with its total
+__device__ __forceinline__ u32 row_scan_add(u32 v) {
+  u32 s = v;
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);   // row_shr:3
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xe, true);   // row_shr:4, banks 1-3
+  s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xc, true);   // row_shr:8, banks 2-3
+  return s;
+}
+// value of lane 15 of the caller's row, in every lane of the row
+__device__ __forceinline__ u32 row_last(u32 v, int lane) {
+  return (u32)__builtin_amdgcn_ds_bpermute(((lane | 15) << 2), (int)v);
+}
+__device__ __forceinline__ u32 row_total(u32 v, int lane) { return row_last(row_scan_add(v), lane); }
+
+// Sixteen lanes per joined path, four paths per wave: a path row is Wp <= 1024 words, a rare-variant cohort has ~80,
+// and everything per path (counts, decisions, list positions) stays in vector registers, uniform inside a row.
+// NIT > 0: the row fits NIT passes of 16 lanes (Wp <= 16 * NIT): all its words are loaded up front, in flight
+// together, and stay in registers for the list pass.  NIT == 0: any width, words are read again for the lists.
+template <int M, int NIT>
+__global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
+  constexpr int NW = NIT > 0 ? NIT : 1;
+  const int lane = threadIdx.x & 63;
+  const int sl = lane & 15;
+  const i64 wave = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const i64 nwaves = (i64)gridDim.x * 4;
+  const int Wp = a.Wp;
+  u32 my_max_tot = 0, my_modes = 0;
+  bool my_bad = false;
+  for (i64 base = wave * 4; base < a.count; base += nwaves * 4) {
+    const bool active = base + (lane >> 4) < a.count;
+    const i64 i = active ? base + (lane >> 4) : a.count - 1;   // idle rows shadow the last path and write nothing
+    const u32 r0 = a.row0[i];
+    const u32 r1raw = a.row1[i];
+    const u32 r1 = r1raw & 0x7fffffffu;
+    const u32 zraw = a.zindex ? (u32)a.zindex[r1] : r1;
+    const u32 rz = zraw & 0x7fffffffu;
+    const u32 zflip = (r1raw ^ (a.zindex ? zraw : 0u)) & 0x80000000u;
+    const u64* x = a.p0 + (size_t)r0 * a.S;
+    const u64* y = a.p1 + (size_t)r1 * a.S;
+    const u64* z = a.pz + (size_t)rz * a.S;
+    u64* out = (a.res && active) ? a.res + (size_t)(a.first + i) * a.S : nullptr;
+    const bool swap = (M == 2) && (r1raw >> 31) != 0;
+    const u64* yh[2] = {swap ? y + Wp : y, swap ? y : y + Wp};
+    const u64* zh[2] = {zflip ? z + Wp : z, zflip ? z : z + Wp};
+
+    // ---- pass 1: counts, 16 bits each, two to a register (64 * Wp < 65535) ----
+    u32 cc[M], dv[M], pe[M];   // carriers among cases | among controls << 16, delta | overlap << 16, popc(x) | extra << 16
+    u64 xw[M][NW], zw[M][NW];  // NIT > 0: the row's words, kept for the list pass
+#pragma unroll
+    for (int h = 0; h < M; h++) cc[h] = dv[h] = pe[h] = 0u;
+    auto tally = [&](int h, int k, u64 xk, u64 yk, u64 zk, u64 cm) {
+      const u64 j = xk | yk;                     // methods.h:77-78 / :164-165
+      if (out) out[h * Wp + k] = j;
+      cc[h] += (u32)__popcll(j & cm) | ((u32)__popcll(j & ~cm) << 16);
+      dv[h] += (u32)__popcll(zk & ~xk) | ((u32)__popcll(zk & xk) << 16);
+      pe[h] += (u32)__popcll(xk) | ((u32)__popcll(zk & ~j) << 16);
+    };
+    if constexpr (NIT > 0) {
+      u64 yw[M][NW], cmw[NW];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int k = it * 16 + sl;
+        const bool in = k < Wp;
+        cmw[it] = in ? a.case_mask[k] : 0;
+#pragma unroll
+        for (int h = 0; h < M; h++) {
+          xw[h][it] = in ? x[h * Wp + k] : 0;
+          yw[h][it] = in ? yh[h][k] : 0;
+          zw[h][it] = in ? zh[h][k] : 0;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int k = it * 16 + sl;
+        if (k < Wp) {
+#pragma unroll
+          for (int h = 0; h < M; h++) tally(h, k, xw[h][it], yw[h][it], zw[h][it], cmw[it]);
+        }
+      }
+    } else {
+      for (int k = sl; k < Wp; k += 16) {
+        const u64 cm = a.case_mask[k];
+#pragma unroll
+        for (int h = 0; h < M; h++) tally(h, k, x[h * Wp + k], yh[h][k], zh[h][k], cm);
+      }
+    }
+    u32 tot[M], mode[M], len[M], inc[M], inm[M];
+#pragma unroll
+    for (int h = 0; h < M; h++) {
+      const u32 c = row_total(cc[h], lane), d = row_total(dv[h], lane), p = row_total(pe[h], lane);
+      inc[h] = c & 0xffffu;      // carriers among the cases
+      inm[h] = c >> 16;          // carriers among the controls
+      tot[h] = inc[h] + inm[h];
+      const u32 dl = d & 0xffffu, ov = d >> 16;
+      mode[h] = (a.ie_bias >= 0 && ov + (u32)a.ie_bias < dl) ? 1u : 0u;
+      len[h] = mode[h] ? ov : dl;
+      // paths0 | reduced row must be the joined row: reduced row inside it, same number of carriers
+      if (active && ((p >> 16) != 0u || (p & 0xffffu) + dl != tot[h])) my_bad = true;
+      if (active && sl == 0) {
+        my_modes += mode[h];
+        my_max_tot = max(my_max_tot, tot[h]);
+      }
+    }
+    if (active && sl == 0) {
+      if constexpr (M == 1) {
+        const double s = a.dvt[(size_t)sp_diag_offset(tot[0]) + inc[0]];   // vt[cases][ctrls], methods.h:90
+        a.key[i] = ie_score_key(s);
+        a.tot[i] = tot[0];
+        a.cases[i] = inc[0];
+        a.ctrls[i] = inm[0];
+      } else {
+        // (+) half: case_pos = inc[0], ctrl_neg = inm[0]; (-) half: ctrl_pos = inc[1], case_neg = inm[1] (methods.h:182-185)
+        const u32 case_pos = inc[0], ctrl_neg = inm[0], ctrl_pos = inc[M - 1], case_neg = inm[M - 1];
+        const double s = a.dvt[(size_t)sp_diag_offset(tot[0]) + case_pos] + a.dvt[(size_t)sp_diag_offset(tot[M - 1]) + case_neg];
+        a.key[i] = ie_score_key(s);
+        a.tot[2 * i] = tot[0];
+        a.tot[2 * i + 1] = tot[M - 1];
+        a.cases[i] = case_pos + case_neg;        // methods.h:256-257
+        a.ctrls[i] = ctrl_pos + ctrl_neg;
+      }
+      a.rowz[i] = rz | zflip;
+    }
+
+    // ---- pass 2: the lists.  Entry = patient << 8 (byte offset of the patient's row in a mask tile) ----
+#pragma unroll
+    for (int h = 0; h < M; h++) {
+      const u64 d = (u64)i * M + h;
+      const u32 len8 = max(8u, (len[h] + 7u) & ~7u);
+      // long lists reserve their tail in the overflow area: one atomic per wave (the four rows' needs added up),
+      // not one per path -- they all hit the same counter
+      const u32 need = (active && len8 > 8u) ? len8 - 8u : 0u;
+      const u32 n0 = rdlane(need, 0), n1 = rdlane(need, 16), n2 = rdlane(need, 32), n3 = rdlane(need, 48);
+      u32 ovb = 0u;
+      if (n0 + n1 + n2 + n3 != 0u) {
+        u32 wbase = 0u;
+        if (lane == 0) wbase = atomicAdd(a.ov_count, n0 + n1 + n2 + n3);
+        wbase = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
+        const int row = lane >> 4;
+        ovb = wbase + (row > 0 ? n0 : 0u) + (row > 1 ? n1 : 0u) + (row > 2 ? n2 : 0u);
+      }
+      const bool ov_ok = active && len8 > 8u && (u64)ovb + (len8 - 8u) <= (u64)a.over_cap;
+      u32* slot = a.slot + d * 8;
+      u32* over = a.over + ovb;
+      u32 run = 0u;
+      auto emit = [&](int k, u64 w) {
+        const u32 c = (u32)__popcll(w);
+        const u32 incl = row_scan_add(c);
+        u32 pos = run + incl - c;
+        while (w) {
+          const u32 b = (u32)__builtin_ctzll(w);
+          w &= w - 1;
+          const u32 e = ((u32)k * 64u + b) << 8;
+          if (pos < 8u) { if (active) slot[pos] = e; }
+          else if (ov_ok) over[pos - 8u] = e;
+          pos++;
+        }
+        run += row_last(incl, lane);
+      };
+      if constexpr (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          if (it * 16 < Wp) emit(it * 16 + sl, mode[h] ? (zw[h][it] & xw[h][it]) : (zw[h][it] & ~xw[h][it]));
+        }
+      } else {
+        for (int k0 = 0; k0 < Wp; k0 += 16) {
+          const int k = k0 + sl;
+          u64 w = 0;
+          if (k < Wp) {
+            const u64 xk = x[h * Wp + k], zk = zh[h][k];
+            w = mode[h] ? (zk & xk) : (zk & ~xk);
+          }
+          emit(k, w);
+        }
+      }
+      for (u32 p = len[h] + (u32)sl; p < len8; p += 16) {   // padding: the all-zero mask row
+        if (p < 8u) { if (active) slot[p] = a.zoff; }
+        else if (ov_ok) over[p - 8u] = a.zoff;
+      }
+      if (active && sl == 0) {
+        a.linfo[d] = len8 | mode[h];
+        a.lover[d] = ovb;
+      }
+    }
+  }
+  if (my_max_tot) atomicMax(a.max_tot, my_max_tot);
+  if (my_bad) *a.bad = 1u;
+  if (my_modes) atomicAdd(a.bad + 1, my_modes);   // statistics: overlap-mode lists
+}
+
+hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {
+  if (a.count == 0) return hipSuccess;
+  const i64 blocks = (a.count + 15) / 16;   // 4 waves x 4 paths per block and pass
+  const dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), block(256);
+  const int nit = (a.Wp + 15) / 16;
+#define GCRE_ST(MM, NN) hipLaunchKernelGGL((k_stats_ie<MM, NN>), grid, block, 0, stream, a)
+  if (method == 1) {
+    if (nit <= 2) GCRE_ST(1, 2); else if (nit <= 4) GCRE_ST(1, 4); else if (nit <= 6) GCRE_ST(1, 6); else if (nit <= 8) GCRE_ST(1, 8); else GCRE_ST(1, 0);
+  } else {
+    if (nit <= 2) GCRE_ST(2, 2); else if (nit <= 4) GCRE_ST(2, 4); else GCRE_ST(2, 0);
+  }
+#undef GCRE_ST
   return hipGetLastError();
 }
 

@@ -101,8 +101,10 @@ struct IeArgs {
   uint32_t rows0, rowsz, rows_out;   // row-halves (rows * M) of the three plane arrays
   const uint64_t* loff0;
   const uint32_t* lidx0;
-  const uint64_t* doff;      // [count*M+1] list offsets (multiples of 8, every list >= 8 entries); bit 0 = mode: 0 delta list, 1 overlap list
-  const uint32_t* dlist;
+  const uint32_t* linfo;     // per list (path*M + half): padded length (multiple of 8, >= 8) | mode (bit 0: 1 = overlap list)
+  const uint32_t* lover;     // per list: where entries 8.. live in `dover` (lists longer than 8)
+  const uint32_t* dlist;     // per list: its first 8 entries at [list*8, list*8+8)
+  const uint32_t* dover;
   const float* t32;
   const double* d64;
   const uint32_t* ladder;    // [kLadderLevels + 2][ladder_stride] hi << 16 | lo (method 1); rows kLadderLevels, +1: all inside / all outside
@@ -176,12 +178,23 @@ struct StatsArgs {
   uint32_t* rowz;              // out: reduced row | swap << 31 per joined path
   uint32_t* bad;               // out: set to 1 when some joined path differs from paths0 | reduced row
   int ie_bias;                 // overlap list chosen when overlap + ie_bias < delta; negative: never
+  // k_stats_ie only: the lists themselves, written in the same pass (no scan, no fill kernel).  List d = path*M + half
+  // has its first 8 entries in slot[d*8 .. d*8+8) and the rest, when it is longer, in over[lover[d] ..); both padded
+  // with `zoff` to a multiple of 8.  linfo[d] = padded length | mode (bit 0: 1 = overlap list).
+  uint32_t* linfo;
+  uint32_t* lover;
+  uint32_t* slot;
+  uint32_t* over;
+  uint32_t over_cap;           // entries `over` can hold; ov_count beyond it means: grow and run again
+  uint32_t* ov_count;          // entries reserved in `over` so far
+  uint32_t zoff;
   int64_t first;
   int64_t count;
   int S;
   int Wp;
 };
 hipError_t launch_stats(const StatsArgs& a, int method, hipStream_t stream);
+hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream);   // gcre_ie.hip
 
 // ---- top-k selection over key[0..count) ----
 hipError_t launch_hist(const uint64_t* key, int64_t count, int shift, uint64_t prefix, uint32_t* hist256,
