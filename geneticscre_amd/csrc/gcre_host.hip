@@ -91,7 +91,7 @@ struct gcre_ctx {
 
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
-  DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan;
+  DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan, d_excess;
   DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz, d_ie_scratch, d_linfo, d_lover, d_dover;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
 
@@ -138,6 +138,12 @@ struct gcre_uids {
   const gcre_pathset* red = nullptr;
   int32_t* d_red_index = nullptr;
   int64_t n_red_index = 0;
+  // distinct (location, count) ranges of the uids (all uids with the same pivot gene share one): built on first use
+  mutable int64_t n_ranges = -1;
+  mutable int32_t* d_range_of = nullptr;    // uid -> range
+  mutable int64_t n_pairs = 0;              // (range, paths1 row) pairs = sum of the range lengths
+  mutable int32_t* d_pair_range = nullptr;
+  mutable int64_t* d_pair_loc = nullptr;
 };
 
 namespace {
@@ -470,7 +476,8 @@ struct JoinPlan {
 void free_uids(gcre_uids* u) {
   if (!u) return;
   if (u->ctx && u->ctx->stream) (void)hipStreamSynchronize(u->ctx->stream);
-  for (void* p : {(void*)u->d_path_idx, (void*)u->d_location, (void*)u->d_signs, (void*)u->d_red_index})
+  for (void* p : {(void*)u->d_path_idx, (void*)u->d_location, (void*)u->d_signs, (void*)u->d_red_index,
+                  (void*)u->d_range_of, (void*)u->d_pair_range, (void*)u->d_pair_loc})
     if (p) (void)hipFree(p);
   for (auto& sc : u->seg_cache)
     if (sc.d_segs) (void)hipFree(sc.d_segs);
@@ -520,6 +527,56 @@ gcre_uids* make_uids(gcre_ctx* c, int path_length, const int32_t* uid_count, con
     return nullptr;
   }
   return u;
+}
+
+// distinct (location, count) ranges of a join index, uid -> range (see k_range_union)
+int ensure_ranges(gcre_ctx* c, const gcre_uids& u) {
+  if (u.n_ranges >= 0) return GCRE_OK;
+  const auto& pi = u.h_path_idx;
+  std::vector<int32_t> range_of((size_t)std::max<int64_t>(u.n_uids, 1), 0);
+  std::vector<int64_t> loc;
+  std::vector<int32_t> cnt;
+  std::unordered_map<uint64_t, int32_t> seen;
+  seen.reserve((size_t)u.n_uids / 8 + 16);
+  for (int64_t i = 0; i < u.n_uids; i++) {
+    const int64_t n = pi[(size_t)i + 1] - pi[(size_t)i];
+    if (n <= 0) continue;   // never joined: its range is never looked at
+    const uint64_t key = ((uint64_t)u.h_location[(size_t)i] << 24) ^ (uint64_t)n;   // locations < 2^31, counts < 2^31
+    auto it = seen.find(key);
+    if (it == seen.end() || loc[(size_t)it->second] != u.h_location[(size_t)i] || cnt[(size_t)it->second] != (int32_t)n) {
+      if (it != seen.end()) {   // a collision of the mixed key: keep both, correctness does not depend on sharing
+        range_of[(size_t)i] = (int32_t)loc.size();
+        loc.push_back(u.h_location[(size_t)i]);
+        cnt.push_back((int32_t)n);
+        continue;
+      }
+      it = seen.emplace(key, (int32_t)loc.size()).first;
+      loc.push_back(u.h_location[(size_t)i]);
+      cnt.push_back((int32_t)n);
+    }
+    range_of[(size_t)i] = it->second;
+  }
+  const size_t R = loc.size();
+  std::vector<int32_t> pair_range;
+  std::vector<int64_t> pair_loc;
+  for (size_t r = 0; r < R; r++)
+    for (int32_t t = 0; t < cnt[r]; t++) {
+      pair_range.push_back((int32_t)r);
+      pair_loc.push_back(loc[r] + t);
+    }
+  const size_t T = pair_range.size();
+  HIP_TRY(c, hipMalloc((void**)&u.d_range_of, range_of.size() * 4));
+  HIP_TRY(c, hipMalloc((void**)&u.d_pair_range, std::max<size_t>(T, 1) * 4));
+  HIP_TRY(c, hipMalloc((void**)&u.d_pair_loc, std::max<size_t>(T, 1) * 8));
+  HIP_TRY(c, hipMemcpyAsync(u.d_range_of, range_of.data(), range_of.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if (T) {
+    HIP_TRY(c, hipMemcpyAsync(u.d_pair_range, pair_range.data(), T * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(u.d_pair_loc, pair_loc.data(), T * 8, hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // the vectors are locals
+  u.n_pairs = (int64_t)T;
+  u.n_ranges = (int64_t)R;
+  return GCRE_OK;
 }
 
 int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
@@ -636,6 +693,26 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       if (int rc = ensure_planes(c, jp.p0)) return rc;     // no-op when a kept join left them behind
       have_p0 = planes_current(c, jp.p0);
       if (!have_p0 || !have_pz) want_ie = false;   // the planes do not fit in device memory: delta streaming (gcre_sparse.hip)
+      if (want_ie && hinted) {
+        // the hint is checked without reading paths1 per joined path: once per distinct uid range here (the reduced
+        // row lies inside paths1[loc]; what paths1[loc] has beyond it is collected per range), and per joined path in
+        // k_stats_ie (that excess lies inside paths0[idx])
+        if (int rc = ensure_ranges(c, u)) return rc;
+        const size_t ewords = (size_t)std::max<int64_t>(u.n_ranges, 1) * g.S;
+        HIP_TRY(c, c->d_excess.reserve(ewords));
+        HIP_TRY(c, hipMemsetAsync(c->d_excess.p, 0, ewords * 8, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 32, st));
+        HIP_TRY(c, launch_range_union(jp.p1->d_rows, red->d_rows, u.d_red_index, u.d_pair_range, u.d_pair_loc, u.n_pairs, g.S,
+                                      g.Wp, g.method, c->d_excess.p, c->d_max_tot + 1, st));
+        uint32_t flag = 0;
+        HIP_TRY(c, hipMemcpyAsync(&flag, c->d_max_tot + 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (flag != 0) {   // the reduced rows are not even part of the rows they stand for: join on paths1 itself
+          hinted = false;
+          if (int rc = prepare_z()) return rc;
+          if (!have_pz) want_ie = false;
+        }
+      }
       if (want_ie && keep) {
         // carriers of a joined row <= carriers(paths0 row) + carriers(added row); <= padded patient count
         const uint32_t bound = std::min<uint32_t>((uint32_t)(64 * g.Wp), row_max(c, jp.p0) + row_max(c, red));
@@ -691,9 +768,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, c->d_linfo.reserve(nl));
           HIP_TRY(c, c->d_lover.reserve(nl));
           HIP_TRY(c, c->d_dlist.reserve(nl * 8 + 16));
-          HIP_TRY(c, c->d_dover.reserve(std::max<size_t>(c->d_dover.cap, nl * 2 + 64)));
+          HIP_TRY(c, c->d_dover.reserve(std::max<size_t>(c->d_dover.cap, nl * 2 + ((size_t)1 << 26))));   // + the waves' chunk slack
           sa.pz = red->d_rows;
           sa.zindex = hinted ? u.d_red_index : nullptr;
+          sa.excess = hinted ? c->d_excess.p : nullptr;
+          sa.range_of = hinted ? u.d_range_of : nullptr;
           sa.rowz = c->d_rowz.p;
           sa.bad = c->d_max_tot + 1;
           sa.ie_bias = 8;
@@ -704,6 +783,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sa.over_cap = (uint32_t)std::min<size_t>(c->d_dover.cap - 16, 0xfffffff0u);
           sa.ov_count = c->d_max_tot + 4;
           sa.zoff = (uint32_t)(64 * g.Wp) << 8;
+          if (const char* e = std::getenv("GCRE_STATS_ABLATE")) sa.ablate = std::atoi(e);
           HIP_TRY(c, launch_stats_ie(sa, g.method, st));
         } else {
           HIP_TRY(c, launch_stats(sa, g.method, st));
@@ -1136,6 +1216,7 @@ void gcre_destroy(gcre_ctx* c) {
   c->d_wkey.release();
   c->d_doff.release();
   c->d_scan.release();
+  c->d_excess.release();
   c->d_dcnt.release();
   c->d_dlist.release();
   c->d_rowz.release();

@@ -939,6 +939,8 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
   const int Wp = a.Wp;
   u32 my_max_tot = 0, my_modes = 0;
   bool my_bad = false;
+  constexpr u32 kOverChunk = 2048;   // entries of the overflow area a wave reserves at a time
+  u32 chunk_at = 0u, chunk_left = 0u;
   for (i64 base = wave * 4; base < a.count; base += nwaves * 4) {
     const bool active = base + (lane >> 4) < a.count;
     const i64 i = active ? base + (lane >> 4) : a.count - 1;   // idle rows shadow the last path and write nothing
@@ -949,27 +951,31 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
     const u32 rz = zraw & 0x7fffffffu;
     const u32 zflip = (r1raw ^ (a.zindex ? zraw : 0u)) & 0x80000000u;
     const u64* x = a.p0 + (size_t)r0 * a.S;
-    const u64* y = a.p1 + (size_t)r1 * a.S;
     const u64* z = a.pz + (size_t)rz * a.S;
+    // The joined row is paths0[idx] | paths1[loc] (methods.h:77-78 / :164-165).  paths1[loc] is never read here:
+    // without a hint z IS paths1[loc]; with one, paths1[loc] = z | excess (k_range_union checked z inside it) and
+    // the union U of the excess over every row this uid joins must lie inside paths0[idx] -- checked below -- so
+    // paths0[idx] | paths1[loc] == paths0[idx] | z for every path of the uid.
+    const u64* uu = a.excess ? a.excess + (size_t)a.range_of[r0] * a.S : nullptr;
     u64* out = (a.res && active) ? a.res + (size_t)(a.first + i) * a.S : nullptr;
     const bool swap = (M == 2) && (r1raw >> 31) != 0;
-    const u64* yh[2] = {swap ? y + Wp : y, swap ? y : y + Wp};
+    const u64* uh[2] = {(uu && swap) ? uu + Wp : uu, (uu && !swap) ? uu + Wp : uu};
     const u64* zh[2] = {zflip ? z + Wp : z, zflip ? z : z + Wp};
 
     // ---- pass 1: counts, 16 bits each, two to a register (64 * Wp < 65535) ----
-    u32 cc[M], dv[M], pe[M];   // carriers among cases | among controls << 16, delta | overlap << 16, popc(x) | extra << 16
+    u32 cc[M], dv[M];          // carriers among cases | among controls << 16, delta | overlap << 16
     u64 xw[M][NW], zw[M][NW];  // NIT > 0: the row's words, kept for the list pass
 #pragma unroll
-    for (int h = 0; h < M; h++) cc[h] = dv[h] = pe[h] = 0u;
-    auto tally = [&](int h, int k, u64 xk, u64 yk, u64 zk, u64 cm) {
-      const u64 j = xk | yk;                     // methods.h:77-78 / :164-165
+    for (int h = 0; h < M; h++) cc[h] = dv[h] = 0u;
+    auto tally = [&](int h, int k, u64 xk, u64 zk, u64 uk, u64 cm) {
+      const u64 j = xk | zk;
       if (out) out[h * Wp + k] = j;
+      if (uk & ~xk) my_bad = true;
       cc[h] += (u32)__popcll(j & cm) | ((u32)__popcll(j & ~cm) << 16);
       dv[h] += (u32)__popcll(zk & ~xk) | ((u32)__popcll(zk & xk) << 16);
-      pe[h] += (u32)__popcll(xk) | ((u32)__popcll(zk & ~j) << 16);
     };
     if constexpr (NIT > 0) {
-      u64 yw[M][NW], cmw[NW];
+      u64 uw[M][NW], cmw[NW];
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
         const int k = it * 16 + sl;
@@ -978,8 +984,8 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
 #pragma unroll
         for (int h = 0; h < M; h++) {
           xw[h][it] = in ? x[h * Wp + k] : 0;
-          yw[h][it] = in ? yh[h][k] : 0;
           zw[h][it] = in ? zh[h][k] : 0;
+          uw[h][it] = (in && uu) ? uh[h][k] : 0;
         }
       }
 #pragma unroll
@@ -987,28 +993,26 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
         const int k = it * 16 + sl;
         if (k < Wp) {
 #pragma unroll
-          for (int h = 0; h < M; h++) tally(h, k, xw[h][it], yw[h][it], zw[h][it], cmw[it]);
+          for (int h = 0; h < M; h++) tally(h, k, xw[h][it], zw[h][it], uw[h][it], cmw[it]);
         }
       }
     } else {
       for (int k = sl; k < Wp; k += 16) {
         const u64 cm = a.case_mask[k];
 #pragma unroll
-        for (int h = 0; h < M; h++) tally(h, k, x[h * Wp + k], yh[h][k], zh[h][k], cm);
+        for (int h = 0; h < M; h++) tally(h, k, x[h * Wp + k], zh[h][k], uu ? uh[h][k] : 0, cm);
       }
     }
     u32 tot[M], mode[M], len[M], inc[M], inm[M];
 #pragma unroll
     for (int h = 0; h < M; h++) {
-      const u32 c = row_total(cc[h], lane), d = row_total(dv[h], lane), p = row_total(pe[h], lane);
+      const u32 c = row_total(cc[h], lane), d = row_total(dv[h], lane);
       inc[h] = c & 0xffffu;      // carriers among the cases
       inm[h] = c >> 16;          // carriers among the controls
       tot[h] = inc[h] + inm[h];
       const u32 dl = d & 0xffffu, ov = d >> 16;
       mode[h] = (a.ie_bias >= 0 && ov + (u32)a.ie_bias < dl) ? 1u : 0u;
       len[h] = mode[h] ? ov : dl;
-      // paths0 | reduced row must be the joined row: reduced row inside it, same number of carriers
-      if (active && ((p >> 16) != 0u || (p & 0xffffu) + dl != tot[h])) my_bad = true;
       if (active && sl == 0) {
         my_modes += mode[h];
         my_max_tot = max(my_max_tot, tot[h]);
@@ -1016,7 +1020,7 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
     }
     if (active && sl == 0) {
       if constexpr (M == 1) {
-        const double s = a.dvt[(size_t)sp_diag_offset(tot[0]) + inc[0]];   // vt[cases][ctrls], methods.h:90
+        const double s = (a.ablate & 2) ? 1.0 : a.dvt[(size_t)sp_diag_offset(tot[0]) + inc[0]];   // vt[cases][ctrls], methods.h:90
         a.key[i] = ie_score_key(s);
         a.tot[i] = tot[0];
         a.cases[i] = inc[0];
@@ -1035,61 +1039,79 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
     }
 
     // ---- pass 2: the lists.  Entry = patient << 8 (byte offset of the patient's row in a mask tile) ----
+    if (a.ablate & 1) continue;
 #pragma unroll
     for (int h = 0; h < M; h++) {
       const u64 d = (u64)i * M + h;
       const u32 len8 = max(8u, (len[h] + 7u) & ~7u);
-      // long lists reserve their tail in the overflow area: one atomic per wave (the four rows' needs added up),
-      // not one per path -- they all hit the same counter
+      // long lists keep their tail in the overflow area.  Every wave carves it out of a private chunk and only goes
+      // to the shared counter for a new chunk (one same-address atomic with return per list costs microseconds)
       const u32 need = (active && len8 > 8u) ? len8 - 8u : 0u;
       const u32 n0 = rdlane(need, 0), n1 = rdlane(need, 16), n2 = rdlane(need, 32), n3 = rdlane(need, 48);
+      const u32 nsum = n0 + n1 + n2 + n3;
       u32 ovb = 0u;
-      if (n0 + n1 + n2 + n3 != 0u) {
-        u32 wbase = 0u;
-        if (lane == 0) wbase = atomicAdd(a.ov_count, n0 + n1 + n2 + n3);
-        wbase = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
+      if (nsum != 0u) {
+        if (chunk_left < nsum) {
+          const u32 grab = nsum > kOverChunk ? nsum : kOverChunk;
+          u32 wbase = 0u;
+          if (lane == 0) wbase = atomicAdd(a.ov_count, grab);
+          chunk_at = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
+          chunk_left = grab;
+        }
         const int row = lane >> 4;
-        ovb = wbase + (row > 0 ? n0 : 0u) + (row > 1 ? n1 : 0u) + (row > 2 ? n2 : 0u);
+        ovb = chunk_at + (row > 0 ? n0 : 0u) + (row > 1 ? n1 : 0u) + (row > 2 ? n2 : 0u);
+        chunk_at += nsum;
+        chunk_left -= nsum;
       }
       const bool ov_ok = active && len8 > 8u && (u64)ovb + (len8 - 8u) <= (u64)a.over_cap;
       u32* slot = a.slot + d * 8;
       u32* over = a.over + ovb;
-      u32 run = 0u;
-      auto emit = [&](int k, u64 w) {
-        const u32 c = (u32)__popcll(w);
-        const u32 incl = row_scan_add(c);
-        u32 pos = run + incl - c;
+      // positions: lane-major inside the row (any order of a list is as good as any other): one row scan of the
+      // lanes' entry counts, then every lane writes its own entries back to back
+      auto word = [&](int it) -> u64 {
+        if constexpr (NIT > 0) {
+          return mode[h] ? (zw[h][it] & xw[h][it]) : (zw[h][it] & ~xw[h][it]);
+        } else {
+          const int k = it * 16 + sl;
+          if (k >= Wp) return 0;
+          const u64 xk = x[h * Wp + k], zk = zh[h][k];
+          return mode[h] ? (zk & xk) : (zk & ~xk);
+        }
+      };
+      const int nit = NIT > 0 ? NIT : (Wp + 15) / 16;
+      u32 mine = 0u;
+      if constexpr (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) mine += (u32)__popcll(word(it));
+      } else {
+        for (int it = 0; it < nit; it++) mine += (u32)__popcll(word(it));
+      }
+      u32 pos = row_scan_add(mine) - mine;
+      auto emit = [&](int it) {
+        u64 w = word(it);
+        const u32 k = (u32)(it * 16 + sl);
         while (w) {
           const u32 b = (u32)__builtin_ctzll(w);
           w &= w - 1;
-          const u32 e = ((u32)k * 64u + b) << 8;
-          if (pos < 8u) { if (active) slot[pos] = e; }
-          else if (ov_ok) over[pos - 8u] = e;
+          const u32 e = (k * 64u + b) << 8;
+          if (!(a.ablate & 4)) {
+            if (pos < 8u) { if (active) slot[pos] = e; }
+            else if (ov_ok) over[pos - 8u] = e;
+          }
           pos++;
         }
-        run += row_last(incl, lane);
       };
       if constexpr (NIT > 0) {
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-          if (it * 16 < Wp) emit(it * 16 + sl, mode[h] ? (zw[h][it] & xw[h][it]) : (zw[h][it] & ~xw[h][it]));
-        }
+        for (int it = 0; it < NIT; it++) emit(it);
       } else {
-        for (int k0 = 0; k0 < Wp; k0 += 16) {
-          const int k = k0 + sl;
-          u64 w = 0;
-          if (k < Wp) {
-            const u64 xk = x[h * Wp + k], zk = zh[h][k];
-            w = mode[h] ? (zk & xk) : (zk & ~xk);
-          }
-          emit(k, w);
-        }
+        for (int it = 0; it < nit; it++) emit(it);
       }
-      for (u32 p = len[h] + (u32)sl; p < len8; p += 16) {   // padding: the all-zero mask row
+      for (u32 p = len[h] + (u32)sl; p < len8 && !(a.ablate & 8); p += 16) {   // padding: the all-zero mask row
         if (p < 8u) { if (active) slot[p] = a.zoff; }
         else if (ov_ok) over[p - 8u] = a.zoff;
       }
-      if (active && sl == 0) {
+      if (active && sl == 0 && !(a.ablate & 16)) {
         a.linfo[d] = len8 | mode[h];
         a.lover[d] = ovb;
       }
@@ -1098,6 +1120,46 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
   if (my_max_tot) atomicMax(a.max_tot, my_max_tot);
   if (my_bad) *a.bad = 1u;
   if (my_modes) atomicAdd(a.bad + 1, my_modes);   // statistics: overlap-mode lists
+}
+
+// Excess of paths1 over the reduced operand, per distinct (location, count) range of the join index:
+//   U[r] = OR over loc in the range of  paths1[loc] & ~z'(loc),   z'(loc) = reduced[index[loc]] in paths1's orientation
+// and the check that z'(loc) lies inside paths1[loc].  One wave per (range, row) pair, OR-ed into U with atomics (the
+// excess is the pivot gene's carriers: a few dozen non-zero words); U is zero on entry.
+__global__ __launch_bounds__(256) void k_range_union(const u64* p1, const u64* pz, const int32_t* zindex, const int32_t* pair_range,
+                                                     const i64* pair_loc, i64 npairs, int S, int Wp, int M, u64* excess,
+                                                     u32* bad) {
+  const int lane = threadIdx.x & 63;
+  const i64 wave = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const i64 nwaves = (i64)gridDim.x * 4;
+  bool my_bad = false;
+  for (i64 p = wave; p < npairs; p += nwaves) {
+    const i64 loc = pair_loc[p];
+    const u32 zraw = (u32)zindex[loc];
+    const u64* zrow = pz + (size_t)(zraw & 0x7fffffffu) * S;
+    const u64* yrow = p1 + (size_t)loc * S;
+    u64* urow = excess + (size_t)pair_range[p] * S;
+    for (int w = lane; w < S; w += 64) {
+      const int h = w / Wp, k = w - h * Wp;
+      const int hz = (M == 2 && (zraw >> 31)) ? 1 - h : h;
+      const u64 zw = zrow[(size_t)hz * Wp + k];
+      const u64 yw = yrow[w];
+      if (zw & ~yw) my_bad = true;
+      const u64 e = yw & ~zw;
+      if (e) atomicOr((unsigned long long*)(urow + w), (unsigned long long)e);
+    }
+  }
+  if (my_bad) *bad = 1u;
+}
+
+hipError_t launch_range_union(const uint64_t* p1, const uint64_t* pz, const int32_t* zindex, const int32_t* pair_range,
+                              const int64_t* pair_loc, int64_t npairs, int S, int Wp, int method, uint64_t* excess,
+                              uint32_t* bad, hipStream_t stream) {
+  if (npairs == 0) return hipSuccess;
+  const i64 blocks = (npairs + 3) / 4;
+  hipLaunchKernelGGL(k_range_union, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream, p1, pz, zindex,
+                     pair_range, pair_loc, npairs, S, Wp, method, excess, bad);
+  return hipGetLastError();
 }
 
 hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {

@@ -181,6 +181,9 @@ struct StatsArgs {
   // k_stats_ie only: the lists themselves, written in the same pass (no scan, no fill kernel).  List d = path*M + half
   // has its first 8 entries in slot[d*8 .. d*8+8) and the rest, when it is longer, in over[lover[d] ..); both padded
   // with `zoff` to a multiple of 8.  linfo[d] = padded length | mode (bit 0: 1 = overlap list).
+  int ablate;                  // diagnostics only (GCRE_STATS_ABLATE)
+  const uint64_t* excess;      // hinted joins: [ranges][S] union of paths1 & ~reduced over each uid range (k_range_union), or nullptr
+  const int32_t* range_of;     // uid (row of paths0) -> its range
   uint32_t* linfo;
   uint32_t* lover;
   uint32_t* slot;
@@ -195,6 +198,9 @@ struct StatsArgs {
 };
 hipError_t launch_stats(const StatsArgs& a, int method, hipStream_t stream);
 hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream);   // gcre_ie.hip
+hipError_t launch_range_union(const uint64_t* p1, const uint64_t* pz, const int32_t* zindex, const int32_t* pair_range,
+                              const int64_t* pair_loc, int64_t npairs, int S, int Wp, int method, uint64_t* excess,
+                              uint32_t* bad, hipStream_t stream);
 
 // ---- top-k selection over key[0..count) ----
 hipError_t launch_hist(const uint64_t* key, int64_t count, int shift, uint64_t prefix, uint32_t* hist256,
