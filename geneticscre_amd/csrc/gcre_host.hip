@@ -896,7 +896,23 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           }
           hipEvent_t n0 = get_event(c), n1 = get_event(c);
           HIP_TRY(c, hipEventRecord(n0, st));
-          HIP_TRY(c, launch_null_ie(ia, g.method, planes, st));
+          ia.seg_begin = 0;
+          ia.seg_end = ia.nsegs;
+          if (g.method == 1 && ia.lad_mode == 0) {
+            // warm-up: the first segments are scored without pruning (every count looked up, general kernel); what
+            // they find seeds the thresholds the pruned kernel starts from.  Joins of a few thousand paths run here whole.
+            const int64_t n_warm = std::min<int64_t>(ia.nsegs, std::max<int64_t>(2048, ia.nsegs / 1024));
+            IeArgs wa = ia;
+            wa.seg_end = n_warm;
+            wa.prune = 0;
+            wa.score_begin = 0;
+            wa.score_end = (uint32_t)n;
+            while (wa.waves_per_xcd > 4 && n_warm < (int64_t)8 * wa.waves_per_xcd)
+              wa.waves_per_xcd = std::max(4, (wa.waves_per_xcd / 2 / 4) * 4);
+            HIP_TRY(c, launch_null_ie(wa, g.method, planes, true, st));
+            ia.seg_begin = n_warm;
+          }
+          if (ia.seg_begin < ia.seg_end) HIP_TRY(c, launch_null_ie(ia, g.method, planes, false, st));
           HIP_TRY(c, hipEventRecord(n1, st));
           if (timing) {
             uint64_t tmv[8] = {0};

@@ -113,18 +113,27 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
     for (int l = 0; l < 16; l++) R[l] = (l < L) ? C[l] : 0u;
     transpose16(R);
   };
-  auto raise = [&](int q, u32 v) {
-    if (v > scr[q * 64]) scr[q * 64] = v;
-  };
-
-  // method 1: counts -> f32 table diagonal -> running maxima (methods.h:96-103)
+  // method 1: counts -> f32 table diagonal -> running maxima (methods.h:96-103).  Eight permutations at a time: their
+  // table cells and their running maxima are independent loads in flight together.
   auto finish_m1 = [&](const u32 (&C)[L], u32 total) {
     u32 R[16];
     to_counts(C, R);
     const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(total);
-    for (int j = 0; j < 16; j++) {
-      raise(j, diag_g[R[j] & 0xffffu]);
-      raise(j + 16, diag_g[R[j] >> 16]);
+#pragma unroll
+    for (int g0 = 0; g0 < 16; g0 += 4) {
+      u32 v[8], o[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        v[k] = diag_g[R[g0 + k] & 0xffffu];
+        v[k + 4] = diag_g[R[g0 + k] >> 16];
+        o[k] = scr[(g0 + k) * 64];
+        o[k + 4] = scr[(g0 + k + 16) * 64];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (v[k] > o[k]) scr[(g0 + k) * 64] = v[k];
+        if (v[k + 4] > o[k + 4]) scr[(g0 + k + 16) * 64] = v[k + 4];
+      }
     }
     dirty = true;
   };
@@ -136,14 +145,27 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
     to_counts(Cn, Rn);
     const double* dp = a.d64 + sp_diag_offset(tp);
     const double* dn = a.d64 + sp_diag_offset(tn);
-    auto one = [&](u32 ca, u32 cb, int q) {
-      float f = (float)(dp[ca] + dn[cb]);
-      f = (f > 0.0f) ? f : 0.0f;
-      raise(q, __float_as_uint(f));
-    };
-    for (int j = 0; j < 16; j++) {
-      one(Rp[j] & 0xffffu, Rn[j] & 0xffffu, j);
-      one(Rp[j] >> 16, Rn[j] >> 16, j + 16);
+#pragma unroll
+    for (int g0 = 0; g0 < 16; g0 += 4) {
+      double sp[8], sn[8];
+      u32 o[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sp[k] = dp[Rp[g0 + k] & 0xffffu];
+        sn[k] = dn[Rn[g0 + k] & 0xffffu];
+        sp[k + 4] = dp[Rp[g0 + k] >> 16];
+        sn[k + 4] = dn[Rn[g0 + k] >> 16];
+        o[k] = scr[(g0 + k) * 64];
+        o[k + 4] = scr[(g0 + k + 16) * 64];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        float f = (float)(sp[k] + sn[k]);
+        f = (f > 0.0f) ? f : 0.0f;
+        const u32 v = __float_as_uint(f);
+        const int q = (k < 4) ? g0 + k : g0 + k - 4 + 16;
+        if (v > o[k]) scr[q * 64] = v;
+      }
     }
     dirty = true;
   };
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
     }
     // thresholds: refresh after 1, 2, 4, .. segments while they are still climbing, then every kIeRefresh
     int since = 0, period = 1;
-    for (i64 sidx = sl; sidx < a.nsegs; sidx += slices) {
+    for (i64 sidx = a.seg_begin + sl; sidx < a.seg_end; sidx += slices) {
       const u32 row0 = segs[sidx].row0;
       const u32 first = segs[sidx].first;
       const u32 npaths = segs[sidx].n;
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
     const i64 item = (i64)xcd * a.nkt * wx + wi + (i64)step * wx;
     const int kt = (int)(item / slices);
     const i64 sl = item % slices;
-    if (sl >= a.nsegs) continue;   // nothing for this wave in this tile
+    if (a.seg_begin + sl >= a.seg_end) continue;   // nothing for this wave in this tile
     if (kt != cur_kt) {
       flush_tile();
       cur_kt = kt;
@@ -486,7 +508,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       if (a.lad_mode == 0) lad_base = 0u;
     }
     int since = 0, period = 1;   // thresholds: refresh after 1, 2, 4, .. segments while they climb, then every kIeRefresh
-    for (i64 sidx = sl; sidx < a.nsegs; sidx += slices) {
+    for (i64 sidx = a.seg_begin + sl; sidx < a.seg_end; sidx += slices) {
       const u32 row0 = segs[sidx].row0;
       const u32 first = segs[sidx].first;
       const u32 npaths = segs[sidx].n;
@@ -725,10 +747,21 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
     else { if (out) { EXPR(16, 4, true); } else { EXPR(16, 4, false); } }                    \
   }
 
-hipError_t launch_null_ie(const IeArgs& a, int method, int planes, hipStream_t stream) {
+#define GCRE_IE_GEN(EXPR)                                          \
+  if (method == 1) {                                               \
+    if (planes <= 8) { EXPR(1, 8); }                               \
+    else if (planes <= 12) { EXPR(1, 12); }                        \
+    else { EXPR(1, 16); }                                          \
+  } else {                                                         \
+    GCRE_IE_M2(EXPR)                                               \
+  }
+
+// general = true: the general kernel (both methods; method 1 then looks every count up -- the warm-up slice that seeds
+// the thresholds, and joins too small for pruning to pay)
+hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general, hipStream_t stream) {
   const dim3 grid((unsigned)(8 * a.waves_per_xcd / kIeWaves));
   const dim3 block(64 * kIeWaves);
-  if (method == 1) {
+  if (method == 1 && !general) {
     const int gz = a.gz;
     const bool out = a.planes_out != nullptr;
 #define GCRE_LAUNCH(LL, GG, OO) hipLaunchKernelGGL((k_null_ie_m1<LL, GG, OO>), grid, block, 0, stream, a)
@@ -736,7 +769,7 @@ hipError_t launch_null_ie(const IeArgs& a, int method, int planes, hipStream_t s
 #undef GCRE_LAUNCH
   } else {
 #define GCRE_LAUNCH(MM, LL) hipLaunchKernelGGL((k_null_ie<MM, LL>), grid, block, 0, stream, a)
-    GCRE_IE_M2(GCRE_LAUNCH)
+    GCRE_IE_GEN(GCRE_LAUNCH)
 #undef GCRE_LAUNCH
   }
   return hipGetLastError();

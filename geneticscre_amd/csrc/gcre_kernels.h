@@ -115,6 +115,7 @@ struct IeArgs {
   uint32_t* planes_out;      // optional: planes of the joined paths [tile][(out_first+q)*M+h][go][64][4]
   int64_t out_first;
   int64_t nsegs;
+  int64_t seg_begin, seg_end;        // slice of the segment table this launch walks
   uint32_t score_begin, score_end;   // joined paths of the launch outside [begin, end) only produce planes
   int nkt, waves_per_xcd, K;
   int g0, gz, go;            // plane groups (4 planes each) of the three plane arrays
@@ -124,7 +125,7 @@ struct IeArgs {
   uint32_t mt_rows, zoff;
   int ablate;                // diagnostics only (GCRE_IE_ABLATE): wrong results, shows where the time goes
 };
-hipError_t launch_null_ie(const IeArgs& a, int method, int planes, hipStream_t stream);
+hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general, hipStream_t stream);
 int ie_max_waves_per_cu(int method, int planes, int gz, bool out);
 hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, const uint64_t* loff, const uint32_t* lidx,
                                int64_t nrowhalves, int groups, uint32_t* planes, hipStream_t stream);
