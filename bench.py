@@ -281,15 +281,42 @@ def main():
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
         "launches": launches, "avg_launch_ms": null_s * 1e3 / launches, "alg_bytes_per_launch": alg_bytes / launches,
     }
-    # HBM traffic per launch from the committed PMC passes of this workload (profiles/), when there is one
+    # HBM traffic per launch and the VALU instruction count per unit of work come from the committed PMC passes of
+    # this workload (profiles/rNN_x_pmc.json, tools/profile_round.sh); time and throughput are measured live
+    ie = prof_acc.get("ie_launches", 0) > 0
+    pmc = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")))
-        if pmc.get("workload") == args.config and not args.edges and not args.perms and row_loads > 0 and world == 1:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc.json" if ie else "r01_b_pmc_traffic.json")))
+        same = pmc.get("workload") == args.config and not args.edges and not args.perms and world == 1
+        if same and (ie or row_loads > 0):
             roofline["traffic"] = pmc["traffic_bytes_per_null_launch"]
-            roofline["traffic_source"] = "profiles/r01_b_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, raw)"
+            roofline["traffic_source"] = ("profiles/%s (rocprofv3 FETCH_SIZE + WRITE_SIZE of the null kernels, raw KB x 1024; "
+                                          "the count planes and lists, not in SURVEY's formula, are most of it)"
+                                          % ("r01_d_pmc.json" if ie else "r01_b_pmc_traffic.json"))
+        else:
+            pmc = pmc if ie else None
     except (OSError, ValueError, KeyError):
-        pass
-    if row_loads > 0:
+        pmc = None
+    if ie:
+        # inclusion-exclusion kernel on count planes: ~100 single-cycle-per-lane-group bit instructions per joined path
+        # and 2048-permutation tile, nothing else of comparable cost -- bound by VALU issue (one wave64 VOP3 per 4 clocks
+        # per SIMD), not by HBM and not by the L2
+        nkt = (K + 2047) // 2048
+        tiles = sum(plan.uids[k].total_paths for k in plan.names) * nkt / max(world, 1)
+        per_tile = 100.0
+        if pmc is not None:
+            valu = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in pmc["kernels"].items() if k.startswith("k_null_ie"))
+            ref_tiles = 28467181.0 * 5          # joined paths x permutation tiles of the profiled run (configs[2])
+            per_tile = valu / ref_tiles if valu > 0 else per_tile
+        peak = 256 * 4 * 2.4e9 / 4.0            # wave64 VALU instructions per second the chip can issue
+        ach = per_tile * tiles * args.steps / null_s if null_s > 0 else 0.0
+        roofline["kernel"] = "k_null_ie_m1 (+ warm-up slice on k_null_ie)"
+        roofline["note"] = ("north-star accounting (algorithmic HBM bytes / kernel time); the kernel is bound by VALU issue, "
+                            "see valu; `launches` counts joins (one warm-up + one pruned launch each)")
+        roofline["valu"] = {"achieved": ach, "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
+                            "instr_per_path_tile": per_tile,
+                            "source": "SQ_INSTS_VALU of the null kernels in profiles/r01_d_pmc.json / path-tiles of that run"}
+    elif row_loads > 0:
         # sparse bit-sliced kernel: bound by the rate at which a CU pulls random 256-byte mask rows out of L2
         # (tools/row_gather_rate.hip measures ~40 G wave-loads/s on this chip), not by HBM and not by the VALU
         roofline["kernel"] = "k_null_sparse"
