@@ -33,8 +33,9 @@ class gcre_result(ctypes.Structure):
 
 
 class gcre_join_opts(ctypes.Structure):
-    _fields_ = [("sharded", ctypes.c_int32), ("reserved", ctypes.c_int32), ("shard_begin", ctypes.c_int64),
-                ("shard_end", ctypes.c_int64), ("d_null_out", ctypes.c_void_p)]
+    _fields_ = [("sharded", ctypes.c_int32), ("keep_ranged", ctypes.c_int32), ("shard_begin", ctypes.c_int64),
+                ("shard_end", ctypes.c_int64), ("d_null_out", ctypes.c_void_p), ("keep_begin", ctypes.c_int64),
+                ("keep_end", ctypes.c_int64)]
 
 
 class gcre_profile(ctypes.Structure):
@@ -367,12 +368,17 @@ class JoinExec:
         return PathSet(self, self._lib.gcre_pathset_from_words(self._h, _ptr(r), r.shape[0]))
 
     def join(self, uids, paths0: PathSet, paths1: PathSet, paths_res: Optional[PathSet] = None,
-             shard: Optional[Tuple[int, int]] = None, d_null_out: int = 0) -> JoinResult:
+             shard: Optional[Tuple[int, int]] = None, d_null_out: int = 0,
+             keep: Optional[Tuple[int, int]] = None) -> JoinResult:
         """JoinExec::join (src/join_base.cpp:189-264).  ``paths_res`` receives the joined rows when given.
-        ``uids`` is a UidRelSet (uploaded for this call) or a DeviceUids (already resident)."""
-        opts = gcre_join_opts(0, 0, 0, 0, None)
+        ``uids`` is a UidRelSet (uploaded for this call) or a DeviceUids (already resident).  ``shard`` restricts
+        scoring to a range of joined paths; ``keep`` restricts the rows written to ``paths_res`` to a range (plus
+        the scored shard) -- the rows this device's shards of the later joins will read."""
+        opts = gcre_join_opts(0, 0, 0, 0, None, 0, 0)
         if shard is not None:
             opts.sharded, opts.shard_begin, opts.shard_end = 1, int(shard[0]), int(shard[1])
+        if keep is not None:
+            opts.keep_ranged, opts.keep_begin, opts.keep_end = 1, int(keep[0]), int(keep[1])
         if d_null_out:
             opts.d_null_out = ctypes.c_void_p(int(d_null_out))
         res = gcre_result()
@@ -511,6 +517,7 @@ class ResidentPlan:
 
     def __init__(self, problem, device: int = 0, packed_masks: Optional[np.ndarray] = None):
         self.problem = problem
+        self._needed: Dict[tuple, Tuple[int, int]] = {}
         ex = self.ex = JoinExec(problem.method, problem.n_cases, problem.n_ctrls, problem.iterations, device)
         ex.top_k = problem.top_k
         ex.set_value_table(problem.value_table)
@@ -565,6 +572,31 @@ class ResidentPlan:
             "5": (k.get("3"), k.get("3"), None),
         }[name]
 
+    def needed_rows(self, name: str, rank: int, world: int) -> Optional[Tuple[int, int]]:
+        """Rows of the set level ``name`` keeps that THIS rank's shards of the later levels read as paths0: level 3's
+        rows are only read through the uids of the level-4 / level-5 shards.  Levels 1 and 2 are small and are also
+        read as paths1 / reduced operands: kept whole."""
+        if world == 1 or name != "3" or "5" in self.uids:   # level 5 reads every row of level 3 as its paths1
+            return None
+        key = (name, rank, world)
+        if key in self._needed:
+            return self._needed[key]
+        lo, hi = None, None
+        for later in ("4",):
+            if later not in self.uids:
+                continue
+            b, e = self.shard(later, rank, world)
+            if e <= b:
+                continue
+            u = self.problem.levels.uids[later]
+            first = np.concatenate([[0], np.cumsum(np.maximum(np.asarray(u.count, dtype=np.int64), 0))])
+            i0 = int(np.searchsorted(first, b, side="right")) - 1          # uid that owns joined path b
+            i1 = int(np.searchsorted(first, e - 1, side="right")) - 1      # uid that owns joined path e-1
+            lo = i0 if lo is None else min(lo, i0)
+            hi = i1 + 1 if hi is None else max(hi, i1 + 1)
+        self._needed[key] = (0, 0) if lo is None else (lo, hi)
+        return self._needed[key]
+
     def shard(self, name: str, rank: int, world: int) -> Tuple[int, int]:
         total = self.uids[name].total_paths
         return (total * rank) // world, (total * (rank + 1)) // world
@@ -575,7 +607,8 @@ class ResidentPlan:
         for name in self.names:
             p0, p1, res = self.operands(name)
             b, e = self.shard(name, rank, world)
-            r = self.ex.join(self.uids[name], p0, p1, res, shard=(b, e) if world > 1 else None, d_null_out=d_null_out)
+            r = self.ex.join(self.uids[name], p0, p1, res, shard=(b, e) if world > 1 else None, d_null_out=d_null_out,
+                             keep=self.needed_rows(name, rank, world))
             for k, v in self.ex.profile().items():
                 prof[k] = prof.get(k, 0) + v
             if on_level is not None:

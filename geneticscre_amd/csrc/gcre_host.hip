@@ -471,6 +471,8 @@ struct JoinPlan {
   bool sharded;
   int64_t shard_begin, shard_end;
   void* d_null_out;
+  bool keep_ranged = false;
+  int64_t keep_begin = 0, keep_end = 0;
 };
 
 void free_uids(gcre_uids* u) {
@@ -634,9 +636,15 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     // segments: rows outside the shard are only materialised (when kept); the shard is scored
     struct Seg { int64_t b, e; bool score; };
     std::vector<Seg> segs;
-    if (keep && sb > 0) segs.push_back({0, sb, false});
+    // kept rows outside the scored shard: all of them, or only [keep_begin, keep_end) (gcre_join_opts.keep_ranged)
+    int64_t kb = 0, ke = P;
+    if (jp.keep_ranged) {
+      kb = std::max<int64_t>(0, std::min(jp.keep_begin, P));
+      ke = std::max(kb, std::min(jp.keep_end, P));
+    }
+    if (keep && kb < std::min(sb, ke)) segs.push_back({kb, std::min(sb, ke), false});
     if (se > sb) segs.push_back({sb, se, true});
-    if (keep && se < P) segs.push_back({se, P, false});
+    if (keep && std::max(se, kb) < ke) segs.push_back({std::max(se, kb), ke, false});
 
     const int64_t tile = cfg.path_tile;
     const int64_t chunk_cap = std::max<int64_t>(tile, (c->chunk_paths / tile) * tile);
@@ -1533,6 +1541,7 @@ int gcre_join(gcre_ctx* c, int path_length, const int32_t* uid_count, const int6
   if (!u) return c->last_code;
   JoinPlan jp{u, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
               opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
+  if (opts && opts->keep_ranged) { jp.keep_ranged = true; jp.keep_begin = opts->keep_begin; jp.keep_end = opts->keep_end; }
   int rc = run_join(c, jp, out);
   free_uids(u);
   if (rc != GCRE_OK) gcre_result_free(out);
@@ -1586,6 +1595,7 @@ int gcre_join_uids(gcre_ctx* c, const gcre_uids* uids, const gcre_pathset* paths
   (void)hipSetDevice(c->device);
   JoinPlan jp{uids, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
               opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
+  if (opts && opts->keep_ranged) { jp.keep_ranged = true; jp.keep_begin = opts->keep_begin; jp.keep_end = opts->keep_end; }
   int rc = run_join(c, jp, out);
   if (rc != GCRE_OK) gcre_result_free(out);
   return rc;

@@ -113,28 +113,23 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
     for (int l = 0; l < 16; l++) R[l] = (l < L) ? C[l] : 0u;
     transpose16(R);
   };
-  // method 1: counts -> f32 table diagonal -> running maxima (methods.h:96-103).  Eight permutations at a time: their
-  // table cells and their running maxima are independent loads in flight together.
+  // method 1: counts -> f32 table diagonal -> running maxima (methods.h:96-103).  All 32 table cells and all 32
+  // running maxima of the lane are independent loads, in flight together.
   auto finish_m1 = [&](const u32 (&C)[L], u32 total) {
     u32 R[16];
     to_counts(C, R);
     const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(total);
+    u32 v[32], o[32];
 #pragma unroll
-    for (int g0 = 0; g0 < 16; g0 += 4) {
-      u32 v[8], o[8];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        v[k] = diag_g[R[g0 + k] & 0xffffu];
-        v[k + 4] = diag_g[R[g0 + k] >> 16];
-        o[k] = scr[(g0 + k) * 64];
-        o[k + 4] = scr[(g0 + k + 16) * 64];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (v[k] > o[k]) scr[(g0 + k) * 64] = v[k];
-        if (v[k + 4] > o[k + 4]) scr[(g0 + k + 16) * 64] = v[k + 4];
-      }
+    for (int j = 0; j < 16; j++) {
+      v[j] = diag_g[R[j] & 0xffffu];
+      v[j + 16] = diag_g[R[j] >> 16];
     }
+#pragma unroll
+    for (int q = 0; q < 32; q++) o[q] = scr[q * 64];
+#pragma unroll
+    for (int q = 0; q < 32; q++)
+      if (v[q] > o[q]) scr[q * 64] = v[q];
     dirty = true;
   };
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GCRE_ABI_VERSION 1
+#define GCRE_ABI_VERSION 2
 
 typedef enum {
   GCRE_OK = 0,
@@ -52,11 +52,15 @@ typedef struct {
 /* Optional knobs of one join.  Zero-initialise for the reference behaviour. */
 typedef struct {
   int32_t sharded;      /* 0: score every joined path (reference behaviour); 1: only [shard_begin, shard_end) */
-  int32_t reserved;
+  int32_t keep_ranged;  /* 0: kept path rows are produced in full, whatever the shard; 1: only rows [keep_begin, keep_end)
+                           and the scored shard are produced -- the rest of `res` is left untouched.  For multi-device runs:
+                           a device only needs the kept rows its own shards of the later joins read */
   int64_t shard_begin;  /* joined-path ordinal range scored on THIS device (may be empty). */
-  int64_t shard_end;    /* Kept path rows are always produced in full, whatever the shard. */
+  int64_t shard_end;
   void* d_null_out;     /* optional device pointer to iterations floats: receives this shard's null maxima
                            (for an RCCL MAX all-reduce by the caller); may be NULL */
+  int64_t keep_begin;   /* joined-path ordinals = rows of `res` (see keep_ranged) */
+  int64_t keep_end;
 } gcre_join_opts;
 
 /* Timing of the last join / process_paths call, measured with HIP events on the library's stream. */

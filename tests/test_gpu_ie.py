@@ -141,3 +141,36 @@ def test_arbitrary_table_prunes_exactly(monkeypatch):
     for lvl in range(1, 5):
         np.testing.assert_array_equal(got[f"lst{lvl}"].null.view(np.uint32), want[f"lst{lvl}"].null.view(np.uint32))
         np.testing.assert_array_equal(got[f"lst{lvl}"].scores, want[f"lst{lvl}"].scores)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_only_keep_the_rows_they_need(world, monkeypatch):
+    """gcre_join_opts.keep_ranged: at level 3 a rank writes the rows its own level-4/5 shards read (plus its scored
+    shard) and nothing else -- the merged results are unchanged and the rows outside stay untouched."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    p = sparse_problem("method1", 10, K=100, L=4)
+    assert api.ResidentPlan(sparse_problem("method1", 10, K=10, L=5)).needed_rows("3", 0, 2) is None   # level 5 reads all of level 3
+    want = oracle.process_paths(p, order="canonical")
+    parts = []
+    for rank in range(world):
+        plan = api.ResidentPlan(p)
+        need = plan.needed_rows("3", rank, world)
+        b, e = plan.shard("3", rank, world)
+        total = plan.uids["3"].total_paths
+        assert 0 <= need[0] <= need[1] <= total and (need[1] - need[0]) < total     # a strict part of the level
+        parts.append(plan.run(rank=rank, world=world))
+        rows = plan.kept["3"].to_numpy()
+        full = want["paths3"]
+        inside = np.zeros(total, bool)
+        inside[need[0]:need[1]] = True
+        inside[b:e] = True
+        np.testing.assert_array_equal(rows[inside], full[inside])
+        assert not rows[~inside].any()                              # never written: still the zeros the set was created with
+        plan.close()
+    for name, lvl in (("3", 3), ("4", 4)):
+        null = np.maximum.reduce([r[name].null for r in parts])
+        rows = [np.stack([r[name].scores, r[name].src, r[name].trg, r[name].cases, r[name].ctrls], axis=1) for r in parts]
+        best = dist.merge_topk(np.vstack(rows), p.top_k)
+        w = want[f"lst{lvl}"]
+        np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
