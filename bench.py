@@ -226,17 +226,18 @@ def main():
     d_null = torch.zeros(max(K, 1), dtype=torch.float32, device=dev)
     prof_acc = {}
 
-    def on_level(name, r, shard):
+    def on_level(name, r, shard, window):
         if world == 1:
             return r
-        # RCCL: MAX all-reduce of the null maxima + all-gather/merge of the top-k tables (geneticscre_amd/dist.py)
+        # RCCL: MAX all-reduce of this window's null maxima + all-gather/merge of the top-k tables (geneticscre_amd/dist.py)
+        k0, k1 = window
         if args.backend == "gloo":   # CPU collectives: stage the maxima through host memory
-            h_null = d_null.cpu()
+            h_null = d_null[k0:k1].cpu()
             best = exchange_level(r.scores, r.src, r.trg, r.cases, r.ctrls, h_null, top_k, world)
-            null = h_null[:K].numpy()
+            null = h_null.numpy()
         else:
-            best = exchange_level(r.scores, r.src, r.trg, r.cases, r.ctrls, d_null, top_k, world, device=dev)
-            null = d_null[:K].cpu().numpy()
+            best = exchange_level(r.scores, r.src, r.trg, r.cases, r.ctrls, d_null[k0:k1], top_k, world, device=dev)
+            null = d_null[k0:k1].cpu().numpy()
         return api.JoinResult(best[:, 0].copy(), best[:, 1].astype(np.int32), best[:, 2].astype(np.int32),
                               best[:, 3].astype(np.int32), best[:, 4].astype(np.int32), null)
 

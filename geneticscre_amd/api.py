@@ -86,6 +86,7 @@ EXPORTS = [
     "gcre_uids_total_paths", "gcre_uids_free", "gcre_join_uids", "gcre_get_profile",
     "gcre_process_paths", "gcre_resolve_count_locs", "gcre_build_levels", "gcre_levels_free", "gcre_values_table",
     "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask", "gcre_uids_set_reduced",
+    "gcre_set_perm_window", "gcre_plan_perm_window",
 ]
 
 
@@ -153,6 +154,8 @@ def load_library():
     lib.gcre_mix64.argtypes = [ctypes.c_uint64]
     lib.gcre_get_perm_mask.argtypes = [V, I, P]
     lib.gcre_uids_set_reduced.argtypes = [V, V, P, I64]
+    lib.gcre_set_perm_window.argtypes = [V, I, I]
+    lib.gcre_plan_perm_window.argtypes = [V, I64]
     _LIB = lib
     return lib
 
@@ -350,6 +353,17 @@ class JoinExec:
             st = np.ascontiguousarray(strata, dtype=np.int32)
             self._check(self._lib.gcre_generate_perm_masks(self._h, int(seed) & (2**64 - 1), _ptr(st), int(st.max()) + 1))
 
+    def set_perm_window(self, k0: int, k1: int) -> None:
+        """Joins that follow score permutations [k0, k1) only (tile aligned); see gcre_set_perm_window."""
+        self._check(self._lib.gcre_set_perm_window(self._h, int(k0), int(k1)))
+
+    def plan_perm_window(self, kept_rows: int) -> int:
+        """Permutations per window so that the count planes of ``kept_rows`` kept rows fit in device memory."""
+        w = self._lib.gcre_plan_perm_window(self._h, int(kept_rows))
+        if w < 0:
+            self._check(w)
+        return max(int(w), 1)
+
     def perm_mask(self, r: int) -> np.ndarray:
         out = np.zeros(self.width_ul, dtype=np.uint64)
         self._check(self._lib.gcre_get_perm_mask(self._h, int(r), _ptr(out)))
@@ -518,6 +532,7 @@ class ResidentPlan:
     def __init__(self, problem, device: int = 0, packed_masks: Optional[np.ndarray] = None):
         self.problem = problem
         self._needed: Dict[tuple, Tuple[int, int]] = {}
+        self._window: Optional[int] = None
         ex = self.ex = JoinExec(problem.method, problem.n_cases, problem.n_ctrls, problem.iterations, device)
         ex.top_k = problem.top_k
         ex.set_value_table(problem.value_table)
@@ -602,18 +617,40 @@ class ResidentPlan:
         return (total * rank) // world, (total * (rank + 1)) // world
 
     def run(self, rank: int = 0, world: int = 1, d_null_out: int = 0, on_level=None) -> Dict[str, JoinResult]:
+        """One pass over all levels.  Large permutation counts run in windows of whole 2048-permutation tiles (the count
+        planes of the kept sets are per tile and have to fit in device memory): all levels for window 0, then all levels
+        for window 1, ...  ``on_level(name, result, shard, window)`` sees every (level, window) result -- its null
+        maxima are those of the window's permutations; ``d_null_out`` (device pointer to K floats) receives them at
+        the window's offset.  The returned results carry the first window's top-k (they do not depend on the window)
+        and the concatenated null maxima."""
+        K = self.problem.iterations
+        if self._window is None:
+            kept = sum(ps.size for ps in self.kept.values()) + sum(ps.size for ps in self.parsed)
+            self._window = self.ex.plan_perm_window(kept) if K > 0 else 1
         out: Dict[str, JoinResult] = {}
+        nulls: Dict[str, list] = {}
         prof: Dict[str, float] = {}
-        for name in self.names:
-            p0, p1, res = self.operands(name)
-            b, e = self.shard(name, rank, world)
-            r = self.ex.join(self.uids[name], p0, p1, res, shard=(b, e) if world > 1 else None, d_null_out=d_null_out,
-                             keep=self.needed_rows(name, rank, world))
-            for k, v in self.ex.profile().items():
-                prof[k] = prof.get(k, 0) + v
-            if on_level is not None:
-                r = on_level(name, r, (b, e))
-            out[name] = r
+        for k0 in range(0, max(K, 1), self._window):
+            k1 = min(K, k0 + self._window)
+            if K > 0:
+                self.ex.set_perm_window(k0, k1)
+            for name in self.names:
+                p0, p1, res = self.operands(name)
+                b, e = self.shard(name, rank, world)
+                r = self.ex.join(self.uids[name], p0, p1, res, shard=(b, e) if world > 1 else None,
+                                 d_null_out=(d_null_out + 4 * k0) if d_null_out else 0,
+                                 keep=self.needed_rows(name, rank, world))
+                for k, v in self.ex.profile().items():
+                    prof[k] = prof.get(k, 0) + v
+                if on_level is not None:
+                    r = on_level(name, r, (b, e), (k0, k1))
+                nulls.setdefault(name, []).append(r.null)
+                if name not in out:
+                    out[name] = r
+        if K > 0:
+            self.ex.set_perm_window(0, K)
+        for name, r in out.items():
+            r.null = np.concatenate(nulls[name]) if len(nulls[name]) > 1 else nulls[name][0]
         self.last_profile = prof
         return out
 

@@ -88,6 +88,9 @@ struct gcre_ctx {
   int sparse_waves_per_cu = 32;
   int ie_prune = 1;                  // GCRE_IE_PRUNE=0 looks every count up (diagnostics)
   uint64_t mask_epoch = 0;           // bumped whenever the permutation masks change: count planes are per epoch
+  // permutation window [win_k0, win_k0 + win_K): what a join scores.  The whole range by default; gcre_set_perm_window
+  // narrows it so that the count planes of the kept sets (one per 2048-permutation tile) fit in device memory
+  int win_k0 = 0, win_K = 0;
 
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
@@ -235,6 +238,8 @@ int build_transposed_masks(gcre_ctx* c) {
   HIP_TRY(c, launch_build_mt(c->d_masks, 2 * g.Wp, g.Kpad, nkt, mt_rows, c->d_mt, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->mask_epoch++;   // every count plane built so far belongs to the old masks
+  c->win_k0 = 0;
+  c->win_K = g.K;
   return GCRE_OK;
 }
 
@@ -311,7 +316,7 @@ bool planes_current(const gcre_ctx* c, const gcre_pathset* ps) {
 }
 
 size_t plane_bytes(const gcre_ctx* c, int64_t nrows, int groups) {
-  const size_t nkt = (size_t)((c->g.K + kSparseTile - 1) / kSparseTile);
+  const size_t nkt = (size_t)((c->win_K + kSparseTile - 1) / kSparseTile);
   return (size_t)std::max<int64_t>(nrows, 1) * c->g.method * nkt * (size_t)groups * 1024;
 }
 
@@ -348,8 +353,9 @@ int ensure_planes(gcre_ctx* c, const gcre_pathset* ps) {
   const int groups = plane_groups_for(ps->max_bits);
   if (!alloc_planes(c, ps, groups)) return GCRE_OK;
   const Geometry& g = c->g;
-  const int nkt = (g.K + kSparseTile - 1) / kSparseTile;
-  HIP_TRY(c, launch_build_planes(c->d_mt, (uint32_t)(64 * g.Wp + 1), nkt, ps->d_loff, ps->d_lidx, ps->nrows * g.method,
+  const int nkt = (c->win_K + kSparseTile - 1) / kSparseTile;
+  const uint32_t* w_mt = c->d_mt + (size_t)(c->win_k0 / kSparseTile) * (size_t)(64 * g.Wp + 1) * 64;
+  HIP_TRY(c, launch_build_planes(w_mt, (uint32_t)(64 * g.Wp + 1), nkt, ps->d_loff, ps->d_lidx, ps->nrows * g.method,
                                  groups, ps->d_planes, c->stream));
   ps->planes_epoch = c->mask_epoch;
   ps->planes_valid = true;
@@ -582,7 +588,15 @@ int ensure_ranges(gcre_ctx* c, const gcre_uids& u) {
 }
 
 int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
-  const Geometry& g = c->g;
+  // the join sees the permutation window (all permutations unless gcre_set_perm_window narrowed it): K, the slice of
+  // the transposed masks, of the masks (row stride stays the full Kpad) and of the maxima
+  Geometry g = c->g;
+  g.K = c->win_K;
+  g.Kpad = ((g.K + kPermTileMax - 1) / kPermTileMax) * kPermTileMax;
+  const int Kstride = c->g.Kpad;
+  uint32_t* const w_null = c->d_null ? c->d_null + c->win_k0 : nullptr;
+  const uint32_t* const w_masks = c->d_masks ? c->d_masks + c->win_k0 : nullptr;
+  const uint32_t* const w_mt = c->d_mt ? c->d_mt + (size_t)(c->win_k0 / kSparseTile) * (size_t)(64 * g.Wp + 1) * 64 : nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   std::memset(out, 0, sizeof *out);
   if (!c->have_table) return fail(c, GCRE_ERR_ASSERT, "value table not set");
@@ -623,7 +637,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
 
   hipStream_t st = c->stream;
   const int Kpad = g.Kpad;
-  if (Kpad > 0) HIP_TRY(c, hipMemsetAsync(c->d_null, 0, (size_t)Kpad * 4, st));
+  if (Kpad > 0) HIP_TRY(c, hipMemsetAsync(w_null, 0, (size_t)Kpad * 4, st));
 
   const NullConfig cfg = null_config(g.method, g.K);
   std::vector<Candidate> cands;
@@ -673,7 +687,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       return 8.0 * g.W * g.method * (up + (double)count) + 8.0 * g.W * g.K + 4.0 * g.K + 24.0 * up;
     };
     // ---- inclusion-exclusion form (gcre_ie.hip): operands and their count planes, once per join ----
-    const bool sparse_ok = sparse_enabled(c) && c->d_mt != nullptr;
+    const bool sparse_ok = sparse_enabled(c) && w_mt != nullptr;
     bool want_ie = sparse_ok && (c->null_kernel == 0 || c->null_kernel == 3);
     const int nkt_sp = (g.K + kSparseTile - 1) / kSparseTile;
     bool hinted = want_ie && u.red && u.red->ctx == c && u.d_red_index && u.n_red_index > u.max_loc;
@@ -839,7 +853,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           IeArgs ia{};
           if (int rc = sparse_segments(c, u, cb, n, &ia.segs, &ia.nsegs)) return rc;
-          ia.mt = c->d_mt;
+          ia.mt = w_mt;
           ia.tot = c->d_tot.p;
           ia.rowz = c->d_rowz.p;
           ia.planes0 = have_p0 ? jp.p0->d_planes : nullptr;
@@ -861,7 +875,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.ladder_stride = g.TD;
           ia.prune = 0;
           ia.lad_mode = !sg.score ? 1 : (c->ie_prune ? 0 : 2);
-          ia.null_bits = c->d_null;
+          ia.null_bits = w_null;
           ia.planes_out = res_planes ? jp.res->d_planes : nullptr;
           ia.go = res_planes ? jp.res->plane_groups : 0;
           ia.out_first = cb;
@@ -981,7 +995,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           SparseArgs sp{};
           if (int rc = sparse_segments(c, u, cb, n, &sp.segs, &sp.nsegs)) return rc;
-          sp.mt = c->d_mt;
+          sp.mt = w_mt;
           sp.tot = c->d_tot.p;
           sp.loff0 = jp.p0->d_loff;
           sp.lidx0 = jp.p0->d_lidx;
@@ -989,7 +1003,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sp.dlist = c->d_dlist.p;
           sp.t32 = c->d_t32;
           sp.d64 = c->d_dmax;
-          sp.null_bits = c->d_null;
+          sp.null_bits = w_null;
           sp.nkt = (g.K + kSparseTile - 1) / kSparseTile;
           sp.mt_rows = (uint32_t)(64 * g.Wp + 1);
           sp.zoff = zoff;
@@ -1026,18 +1040,18 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           NullArgs na{};
           na.p0 = (const uint32_t*)jp.p0->d_rows;
           na.p1 = (const uint32_t*)jp.p1->d_rows;
-          na.masks = c->d_masks;
+          na.masks = w_masks;
           na.row0 = c->d_row0.p;
           na.row1 = c->d_row1.p;
           na.tot = c->d_tot.p;
           na.t32 = c->d_t32;
           na.d64 = c->d_dmax;
-          na.null_bits = c->d_null;
+          na.null_bits = w_null;
           na.npaths = n;
           na.npt = npt;
           na.S32 = 2 * g.S;
           na.W32p = 2 * g.Wp;
-          na.Kpad = Kpad;
+          na.Kpad = Kstride;
           na.nkt = (g.K + cfg.perm_tile - 1) / cfg.perm_tile;
           int dev_cus = 256;
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
@@ -1104,8 +1118,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   out->n_perm = g.K;
   out->null_max = (float*)std::calloc((size_t)std::max(g.K, 1), sizeof(float));
   if (g.K > 0) {
-    HIP_TRY(c, hipMemcpyAsync(out->null_max, c->d_null, (size_t)g.K * 4, hipMemcpyDeviceToHost, st));
-    if (jp.d_null_out) HIP_TRY(c, hipMemcpyAsync(jp.d_null_out, c->d_null, (size_t)g.K * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(out->null_max, w_null, (size_t)g.K * 4, hipMemcpyDeviceToHost, st));
+    if (jp.d_null_out) HIP_TRY(c, hipMemcpyAsync(jp.d_null_out, w_null, (size_t)g.K * 4, hipMemcpyDeviceToDevice, st));
   }
   HIP_TRY(c, hipStreamSynchronize(st));
 
@@ -1196,6 +1210,8 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   g.K = iterations;
   g.Kpad = ((iterations + kPermTileMax - 1) / kPermTileMax) * kPermTileMax;
   g.TD = 64 * g.Wp + 1;
+  c->win_k0 = 0;
+  c->win_K = g.K;
   if (const char* e = std::getenv("GCRE_QUIET")) c->quiet = std::atoi(e) != 0;
   if (const char* e = std::getenv("GCRE_CHUNK_PATHS")) c->chunk_paths = std::max<long long>(64, std::atoll(e));
   if (const char* e = std::getenv("GCRE_NULL_BLOCKS_PER_CU")) c->null_blocks_per_cu = std::max(1, std::atoi(e));
@@ -1401,6 +1417,36 @@ int gcre_generate_perm_masks(gcre_ctx* c, uint64_t seed, const int32_t* stratum,
   if (int rc = build_transposed_masks(c)) return rc;
   c->have_perms = true;
   return GCRE_OK;
+}
+
+int gcre_set_perm_window(gcre_ctx* c, int k0, int k1) {
+  if (!c) return GCRE_ERR_ARG;
+  const int K = c->g.K;
+  if (k0 < 0 || k1 < k0 || k1 > K || (k0 % kSparseTile) != 0 || (k1 != K && (k1 % kSparseTile) != 0))
+    return fail(c, GCRE_ERR_ARG, "permutation window must be tile-aligned (2048) and inside [0, iterations]");
+  if (k0 != c->win_k0 || k1 - k0 != c->win_K) {
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->win_k0 = k0;
+    c->win_K = k1 - k0;
+    c->mask_epoch++;   // count planes hold the tiles of one window
+  }
+  return GCRE_OK;
+}
+
+int gcre_plan_perm_window(gcre_ctx* c, int64_t kept_rows) {
+  if (!c || kept_rows < 0) return GCRE_ERR_ARG;
+  const int K = c->g.K;
+  const int nkt = (K + kSparseTile - 1) / kSparseTile;
+  if (nkt <= 1 || !sparse_enabled(c)) return K;
+  (void)hipSetDevice(c->device);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return K;
+  const double per_tile = (double)std::max<int64_t>(kept_rows, 1) * c->g.method * 4096.0;
+  int64_t tiles = (int64_t)((double)free_b * 0.5 / per_tile);
+  if (const char* e = std::getenv("GCRE_WINDOW_TILES")) tiles = std::max(1, std::atoi(e));   // tests
+  if (tiles >= nkt) return K;
+  return (int)std::max<int64_t>(tiles, 1) * kSparseTile;
 }
 
 int gcre_get_perm_mask(gcre_ctx* c, int r, uint64_t* out) {
@@ -1712,77 +1758,113 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
   } while (0)
 
   const int ncol = c->g.n;
-  parsed1 = gcre_pathset_from_dense(c, in->data1, in->data1_rows, ncol, in->data_col_major);   // wrapper.cpp:216-217
-  PP_REQUIRE(parsed1);
-
-  if (L >= 1) {   // wrapper.cpp:225-244
-    if (!c->quiet) std::printf("Processing Path Length: %d\n", 1);
-    paths1 = new_pathset(c, total_paths(in->level[0]), true);
-    PP_REQUIRE(paths1);
-    gcre_pathset* zero1 = gcre_pathset_zeros(c, in->n_data_inds[0]);
-    PP_REQUIRE(zero1);
-    temps.push_back(zero1);
-    gcre_pathset* input1 = gcre_pathset_select(c, parsed1, in->data_inds[0], in->n_data_inds[0]);
-    PP_REQUIRE(input1);
-    temps.push_back(input1);
-    PP_TRY(join(1, in->level[0], zero1, input1, paths1, nullptr, parsed1, in->data_inds[0], in->n_data_inds[0]));   // result discarded, wrapper.cpp:233
-
-    if (!c->quiet) std::printf("Processing Path Length: %d\n", 1);
-    gcre_pathset* zero2 = gcre_pathset_zeros(c, in->n_data_inds[1]);
-    PP_REQUIRE(zero2);
-    temps.push_back(zero2);
-    parsed2 = gcre_pathset_from_dense(c, in->data2, in->data2_rows, ncol, in->data_col_major);
-    PP_REQUIRE(parsed2);
-    gcre_pathset* input2 = gcre_pathset_select(c, parsed2, in->data_inds[1], in->n_data_inds[1]);
-    PP_REQUIRE(input2);
-    temps.push_back(input2);
-    PP_TRY(join(1, in->level[1], zero2, input2, nullptr, &out[0], parsed2, in->data_inds[1], in->n_data_inds[1]));
-  }
-  if (L >= 2) {   // wrapper.cpp:246-253
-    if (!c->quiet) std::printf("Processing Path Length: %d\n", 2);
-    paths2 = new_pathset(c, total_paths(in->level[2]), true);
-    PP_REQUIRE(paths2);
-    // the reference reads data_idx2 from r_data_inds3 (wrapper.cpp:207); R passes identical vectors
-    gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
-    PP_REQUIRE(input);
-    temps.push_back(input);
-    PP_TRY(join(2, in->level[2], paths1, input, paths2, &out[1], parsed1, in->data_inds[3], in->n_data_inds[3]));
-  }
-  if (L >= 3) {   // wrapper.cpp:255-262
-    if (!c->quiet) std::printf("Processing Path Length: %d\n", 3);
-    paths3 = new_pathset(c, total_paths(in->level[3]), true);
-    PP_REQUIRE(paths3);
-    gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
-    PP_REQUIRE(input);
-    temps.push_back(input);
-    PP_TRY(join(3, in->level[3], paths2, input, paths3, &out[2], parsed1, in->data_inds[3], in->n_data_inds[3]));
-  }
-  if (L >= 4) {   // wrapper.cpp:264-269
-    if (!c->quiet) std::printf("Processing Path Length: %d\n", 4);
-    // paths2[loc] = (c, d) with c already on paths3[idx]: the join adds gene d = the data row level 2 joined at loc
-    // (signed method: level 2 put d into the (-) half when the relation's sign is not 1, gcre.h:71-81 -> bit 31)
-    std::vector<int32_t> added((size_t)in->n_data_inds[3]);
-    for (int64_t i = 0; i < in->n_data_inds[3]; i++) {
-      const bool neg = c->g.method == 2 && i < in->level[2].n_signs && in->level[2].signs[i] != 1;
-      added[(size_t)i] = (int32_t)((uint32_t)in->data_inds[3][i] | (neg ? 0x80000000u : 0u));
-    }
-    PP_TRY(join(4, in->level[4], paths3, paths2, nullptr, &out[3], parsed1, added.data(), (int64_t)added.size()));
-  }
-  if (L >= 5) {   // wrapper.cpp:271-276
-    if (!c->quiet) std::printf("Processing Path Length: %d\n", 5);
-    // paths3[loc] = (c, d, e) with c on paths3[idx]: the join adds the 2-gene path (d, e) = paths2[second relation],
-    // and the second relation of joined path q of level 3 is the paths1 row it joined: location3[uid] + offset
-    std::vector<int32_t> second;
-    {
-      const gcre_level& l3 = in->level[3];
-      for (int64_t i = 0; i < l3.n_uids; i++) {
-        // signed method: (d, e) sits in paths3[loc] with both halves swapped when the relation (c, d) is not positive
-        const bool neg = c->g.method == 2 && i < l3.n_signs && l3.signs[i] != 1;
-        for (int32_t t = 0; t < l3.uid_count[i]; t++)
-          second.push_back((int32_t)((uint32_t)(l3.uid_location[i] + t) | (neg ? 0x80000000u : 0u)));
+  // Large permutation counts run in windows of whole 2048-permutation tiles: the count planes of the kept sets are per
+  // tile, and a window is as many tiles as fit next to the rows.  Scores and top-k lists do not depend on the window (the
+  // first window's are returned); the null maxima of the windows are concatenated.
+  int64_t kept_rows = in->data1_rows + in->data2_rows;
+  for (int lv = 0; lv < 4 && lv <= L; lv++)
+    if (lv != 1) kept_rows += total_paths(in->level[lv]);
+  const int Kall = c->g.K;
+  const int win = std::max(1, gcre_plan_perm_window(c, kept_rows));
+  std::vector<float> null_all[5];
+  for (int k0 = 0; k0 < std::max(Kall, 1); k0 += win) {
+    const bool first_window = k0 == 0;
+    if (Kall > 0) PP_TRY(gcre_set_perm_window(c, k0, std::min(Kall, k0 + win)));
+    gcre_result wout[5];
+    for (int i = 0; i < 5; i++) { std::memset(&wout[i], 0, sizeof wout[i]); wout[i].n = -1; }
+    gcre_result* const out_w = first_window ? out : wout;
+    auto fold = [&]() {   // this window's maxima behind the ones we have; later windows only contribute maxima
+      for (int i = 0; i < 5; i++) {
+        if (out_w[i].n < 0) continue;
+        null_all[i].insert(null_all[i].end(), out_w[i].null_max, out_w[i].null_max + out_w[i].n_perm);
+        if (!first_window) gcre_result_free(&out_w[i]);
       }
+    };
+    (void)fold;
+    if (!parsed1) parsed1 = gcre_pathset_from_dense(c, in->data1, in->data1_rows, ncol, in->data_col_major);   // wrapper.cpp:216-217
+    PP_REQUIRE(parsed1);
+
+    if (L >= 1) {   // wrapper.cpp:225-244
+      if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 1);
+      if (!paths1) paths1 = new_pathset(c, total_paths(in->level[0]), true);
+      PP_REQUIRE(paths1);
+      gcre_pathset* zero1 = gcre_pathset_zeros(c, in->n_data_inds[0]);
+      PP_REQUIRE(zero1);
+      temps.push_back(zero1);
+      gcre_pathset* input1 = gcre_pathset_select(c, parsed1, in->data_inds[0], in->n_data_inds[0]);
+      PP_REQUIRE(input1);
+      temps.push_back(input1);
+      PP_TRY(join(1, in->level[0], zero1, input1, paths1, nullptr, parsed1, in->data_inds[0], in->n_data_inds[0]));   // result discarded, wrapper.cpp:233
+
+      if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 1);
+      gcre_pathset* zero2 = gcre_pathset_zeros(c, in->n_data_inds[1]);
+      PP_REQUIRE(zero2);
+      temps.push_back(zero2);
+      if (!parsed2) parsed2 = gcre_pathset_from_dense(c, in->data2, in->data2_rows, ncol, in->data_col_major);
+      PP_REQUIRE(parsed2);
+      gcre_pathset* input2 = gcre_pathset_select(c, parsed2, in->data_inds[1], in->n_data_inds[1]);
+      PP_REQUIRE(input2);
+      temps.push_back(input2);
+      PP_TRY(join(1, in->level[1], zero2, input2, nullptr, &out_w[0], parsed2, in->data_inds[1], in->n_data_inds[1]));
     }
-    PP_TRY(join(5, in->level[5], paths3, paths3, nullptr, &out[4], paths2, second.data(), (int64_t)second.size()));
+    if (L >= 2) {   // wrapper.cpp:246-253
+      if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 2);
+      if (!paths2) paths2 = new_pathset(c, total_paths(in->level[2]), true);
+      PP_REQUIRE(paths2);
+      // the reference reads data_idx2 from r_data_inds3 (wrapper.cpp:207); R passes identical vectors
+      gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
+      PP_REQUIRE(input);
+      temps.push_back(input);
+      PP_TRY(join(2, in->level[2], paths1, input, paths2, &out_w[1], parsed1, in->data_inds[3], in->n_data_inds[3]));
+    }
+    if (L >= 3) {   // wrapper.cpp:255-262
+      if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 3);
+      if (!paths3) paths3 = new_pathset(c, total_paths(in->level[3]), true);
+      PP_REQUIRE(paths3);
+      gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
+      PP_REQUIRE(input);
+      temps.push_back(input);
+      PP_TRY(join(3, in->level[3], paths2, input, paths3, &out_w[2], parsed1, in->data_inds[3], in->n_data_inds[3]));
+    }
+    if (L >= 4) {   // wrapper.cpp:264-269
+      if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 4);
+      // paths2[loc] = (c, d) with c already on paths3[idx]: the join adds gene d = the data row level 2 joined at loc
+      // (signed method: level 2 put d into the (-) half when the relation's sign is not 1, gcre.h:71-81 -> bit 31)
+      std::vector<int32_t> added((size_t)in->n_data_inds[3]);
+      for (int64_t i = 0; i < in->n_data_inds[3]; i++) {
+        const bool neg = c->g.method == 2 && i < in->level[2].n_signs && in->level[2].signs[i] != 1;
+        added[(size_t)i] = (int32_t)((uint32_t)in->data_inds[3][i] | (neg ? 0x80000000u : 0u));
+      }
+      PP_TRY(join(4, in->level[4], paths3, paths2, nullptr, &out_w[3], parsed1, added.data(), (int64_t)added.size()));
+    }
+    if (L >= 5) {   // wrapper.cpp:271-276
+      if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 5);
+      // paths3[loc] = (c, d, e) with c on paths3[idx]: the join adds the 2-gene path (d, e) = paths2[second relation],
+      // and the second relation of joined path q of level 3 is the paths1 row it joined: location3[uid] + offset
+      std::vector<int32_t> second;
+      {
+        const gcre_level& l3 = in->level[3];
+        for (int64_t i = 0; i < l3.n_uids; i++) {
+          // signed method: (d, e) sits in paths3[loc] with both halves swapped when the relation (c, d) is not positive
+          const bool neg = c->g.method == 2 && i < l3.n_signs && l3.signs[i] != 1;
+          for (int32_t t = 0; t < l3.uid_count[i]; t++)
+            second.push_back((int32_t)((uint32_t)(l3.uid_location[i] + t) | (neg ? 0x80000000u : 0u)));
+        }
+      }
+      PP_TRY(join(5, in->level[5], paths3, paths3, nullptr, &out_w[4], paths2, second.data(), (int64_t)second.size()));
+    }
+    fold();
+    for (auto* p : temps) gcre_pathset_free(p);   // this window's operand copies
+    temps.clear();
+    if (Kall == 0) break;
+  }
+  if (Kall > 0) PP_TRY(gcre_set_perm_window(c, 0, Kall));
+  for (int i = 0; i < 5; i++) {
+    if (out[i].n < 0 || Kall == 0) continue;
+    std::free(out[i].null_max);
+    out[i].n_perm = Kall;
+    out[i].null_max = (float*)std::calloc((size_t)Kall, sizeof(float));
+    std::memcpy(out[i].null_max, null_all[i].data(), (size_t)Kall * sizeof(float));
   }
   if (!c->quiet) std::printf("[success]\n");   // wrapper.cpp:278
   cleanup();

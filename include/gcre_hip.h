@@ -234,6 +234,15 @@ int gcre_values_table(int n_cases, int n_ctrls, double* out);
  * gcre_mix64 and k_generate_masks.  Replaces gcre_set_perm_cases for callers that do not need R's RNG stream. */
 int gcre_generate_perm_masks(gcre_ctx* ctx, uint64_t seed, const int32_t* stratum, int n_strata);
 uint64_t gcre_mix64(uint64_t z);
+/* Restrict the joins that follow to permutations [k0, k1) (k0 a multiple of 2048; k1 a multiple of 2048 or = iterations).
+ * A join then returns k1 - k0 null maxima; observed scores and top-k lists do not depend on the window.  Lets a caller
+ * run a large permutation count in batches whose count planes (one per kept row and 2048-permutation tile) fit in device
+ * memory -- gcre_process_paths does so on its own.  Setting masks resets the window to [0, iterations). */
+int gcre_set_perm_window(gcre_ctx* ctx, int k0, int k1);
+/* Window length (permutations; a multiple of 2048, or iterations when everything fits) for a pipeline whose kept path sets
+ * hold `kept_rows` rows in total: their count planes take up to 4 KB per row, method half and tile, and should leave half
+ * of the free device memory alone. */
+int gcre_plan_perm_window(gcre_ctx* ctx, int64_t kept_rows);
 /* read permutation mask r back as width_ul words (bit c = patient c is a case under permutation r) */
 int gcre_get_perm_mask(gcre_ctx* ctx, int r, uint64_t* out);
 

@@ -174,3 +174,41 @@ def test_ranks_only_keep_the_rows_they_need(world, monkeypatch):
         w = want[f"lst{lvl}"]
         np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
         np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+@pytest.mark.parametrize("tiles", ["1", "2"])
+def test_permutation_windows_change_nothing(method, tiles, monkeypatch):
+    """Large permutation counts run in windows of whole tiles (gcre_set_perm_window; the count planes are per tile).
+    Forced down to 1- and 2-tile windows over 5000 permutations (3 tiles, the last one partial): gcre_process_paths
+    and the resident plan -- sharded over two ranks as well -- return what a single window returns."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_WINDOW_TILES", tiles)
+    p = sparse_problem(method, 13, K=5000, L=5, genes=40, edges=110)
+    want = oracle.process_paths(p, order="canonical")
+    got = api.process_paths(p)
+    check_levels(got, want, range(1, 6))
+    parts = []
+    for rank in range(2):
+        plan = api.ResidentPlan(p)
+        assert plan.ex.plan_perm_window(10) == 2048 * int(tiles)
+        parts.append(plan.run(rank=rank, world=2))
+        plan.close()
+    for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4), ("5", 5)):
+        null = np.maximum(parts[0][name].null, parts[1][name].null)
+        rows = [np.stack([r[name].scores, r[name].src, r[name].trg, r[name].cases, r[name].ctrls], axis=1) for r in parts]
+        best = dist.merge_topk(np.vstack(rows), p.top_k)
+        w = want[f"lst{lvl}"]
+        assert len(null) == 5000
+        np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
+
+
+def test_perm_window_arguments():
+    ex = api.JoinExec("method1", 40, 40, 5000)
+    ex.set_perm_window(2048, 4096)
+    ex.set_perm_window(4096, 5000)          # the last window may end at iterations
+    for bad in ((100, 2048), (0, 3000), (4096, 2048), (0, 6000)):
+        with pytest.raises(api.GcreError):
+            ex.set_perm_window(*bad)
+    ex.close()
