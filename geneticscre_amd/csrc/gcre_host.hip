@@ -805,7 +805,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sa.over_cap = (uint32_t)std::min<size_t>(c->d_dover.cap - 16, 0xfffffff0u);
           sa.ov_count = c->d_max_tot + 4;
           sa.zoff = (uint32_t)(64 * g.Wp) << 8;
-          if (const char* e = std::getenv("GCRE_STATS_ABLATE")) sa.ablate = std::atoi(e);
           HIP_TRY(c, launch_stats_ie(sa, g.method, st));
         } else {
           HIP_TRY(c, launch_stats(sa, g.method, st));
@@ -873,7 +872,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.d64 = c->d_dmax;
           ia.ladder = c->d_ladder;
           ia.ladder_stride = g.TD;
-          ia.prune = 0;
           ia.lad_mode = !sg.score ? 1 : (c->ie_prune ? 0 : 2);
           ia.null_bits = w_null;
           ia.planes_out = res_planes ? jp.res->d_planes : nullptr;
@@ -885,10 +883,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.K = g.K;
           ia.mt_rows = (uint32_t)(64 * g.Wp + 1);
           ia.zoff = zoff;
-          if (const char* e = std::getenv("GCRE_IE_ABLATE")) {   // diagnostics: wrong results
-            ia.ablate = std::atoi(e);
-            if (ia.ablate & 16) ia.lad_mode = 1;
-          }
           c->prof.null_row_loads += ((have_p0 ? 0.0 : (double)row_max(c, jp.p0) * g.method * (double)nseg_est) + (double)n_list) * nkt_sp;
           int dev_cus = 256;
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
@@ -926,7 +920,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             const int64_t n_warm = std::min<int64_t>(ia.nsegs, std::max<int64_t>(2048, ia.nsegs / 1024));
             IeArgs wa = ia;
             wa.seg_end = n_warm;
-            wa.prune = 0;
             wa.score_begin = 0;
             wa.score_end = (uint32_t)n;
             while (wa.waves_per_xcd > 4 && n_warm < (int64_t)8 * wa.waves_per_xcd)

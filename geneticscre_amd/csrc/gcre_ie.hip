@@ -43,8 +43,8 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
 
 __device__ __forceinline__ u32 rdlane(u32 v, u32 t) { return (u32)__builtin_amdgcn_readlane((int)v, (int)t); }
 
-// L = counter planes of the joined paths, a multiple of 4.  No LDS, few registers: the kernel lives on occupancy
-// (the per-path critical path is: 8 mask-row loads + the added row's planes -> ~100 bit operations -> compare).
+// The general kernel: both methods, every count looked up (no pruning).  Runs the signed method, and for method 1 the
+// warm-up slice that seeds the pruned kernel's thresholds.  L = counter planes of the joined paths, a multiple of 4.
 template <int M, int L>
 __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M == 1 ? 4 : 2))) void k_null_ie(const IeArgs a) {
   static_assert(L % 4 == 0 && L >= 8 && L <= 16, "planes come in groups of 4");
@@ -64,37 +64,8 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
   const u32 GCRE_CONSTANT* lidx0 = (const u32 GCRE_CONSTANT*)a.lidx0;
 
   int cur_kt = -1;
-  u32 valid = 0u;       // bit q: permutation 32*lane + q of the tile exists (< K)
-  u32 lad_base = 0u;    // ladder row of the threshold level in use
-  bool dirty = false;   // the strip holds maxima the global array has not seen
-  u32 n_slow = 0u;      // statistics: joined-path tiles that reached the table lookup
   __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)a.mt, 0, 0x7fffffff, 0x00020000);
 
-  // publish the wave's maxima, read everybody's, and set the pruning threshold to the smallest running maximum of
-  // the tile's live permutations (a stale read only lowers it: still exact)
-  auto exchange = [&]() {
-    u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
-    u32 lo = 0xffffffffu;
-#pragma unroll 8
-    for (int q = 0; q < 32; q++) {
-      const u32 g = __hip_atomic_load(out + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past the L1
-      u32 v = g;
-      if (dirty) {
-        const u32 own = scr[q * 64];
-        if (own > g) {
-          atomicMax(out + q, own);
-          v = own;
-        }
-      }
-      if ((valid >> q) & 1u) lo = v < lo ? v : lo;
-    }
-    dirty = false;
-    u32 theta = __builtin_amdgcn_readfirstlane(wave_min_u32(lo));
-    if (theta == 0xffffffffu) theta = 0u;
-    int j = (int)(__uint_as_float(theta) * (float)kLadderPerUnit);   // level j covers thresholds >= j / kLadderPerUnit
-    j = j < 0 ? 0 : (j > kLadderLevels - 1 ? kLadderLevels - 1 : j);
-    lad_base = (u32)j * (u32)a.ladder_stride;
-  };
   auto flush = [&]() {
     if (cur_kt < 0) return;
     u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
@@ -105,7 +76,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
         scr[q * 64] = 0u;
       }
     }
-    dirty = false;
   };
 
   auto to_counts = [&](const u32 (&C)[L], u32 (&R)[16]) {
@@ -130,7 +100,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
 #pragma unroll
     for (int q = 0; q < 32; q++)
       if (v[q] > o[q]) scr[q * 64] = v[q];
-    dirty = true;
   };
 
   // method 2: vtmax[a][tp-a] + vtmax[tn-b][b] in f64, rounded to f32, clamped at 0 (methods.h:220-230)
@@ -162,36 +131,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
         if (v > o[k]) scr[q * 64] = v;
       }
     }
-    dirty = true;
-  };
-
-  // Per lane the live permutations whose count lies outside [lo, hi].  Two borrow chains over the planes, scalar
-  // bound bits:  C < lo  <=>  C - lo borrows;  C > hi  <=>  hi - C borrows.
-  auto outside = [&](const u32 (&C)[L], u32 lo, u32 hi) -> u32 {
-    u32 blo = 0u, bhi = 0u;
-#pragma unroll
-    for (int l = 0; l < L; l++) {
-      const u32 kl = (u32)__builtin_amdgcn_sbfe((int)lo, l, 1);   // scalar: all ones when the bound has bit l
-      const u32 kh = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
-      blo = maj3(~C[l], kl, blo);
-      bhi = maj3(~kh, C[l], bhi);
-    }
-    return (blo | bhi) & valid;
-  };
-
-  // method 1, the few permutations that passed the test: rebuild each one's count from the planes, look it up
-  auto finish_some = [&](const u32 (&C)[L], u32 total, u32 m) {
-    const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(total);
-    while (m != 0u) {
-      const u32 b = (u32)__builtin_ctz(m);
-      m &= m - 1u;
-      u32 cnt = 0u;
-#pragma unroll
-      for (int l = 0; l < L; l++) cnt |= ((C[l] >> b) & 1u) << l;
-      const u32 v = diag_g[cnt];
-      if (v > scr[b * 64]) scr[b * 64] = v;
-    }
-    dirty = true;
   };
 
   // count planes of one (row-half, tile): `unit` = ((row*M + half) * nkt + tile) * groups; groups of 4 planes,
@@ -217,22 +156,11 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
       flush();
       cur_kt = kt;
       mt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mt + (size_t)kt * a.mt_rows * 64), 0, 0x7fffffff, 0x00020000);
-      const int live = a.K - kt * 2048 - lane * 32;           // permutations of this lane that exist
-      valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
-      lad_base = 0u;
     }
-    // thresholds: refresh after 1, 2, 4, .. segments while they are still climbing, then every kIeRefresh
-    int since = 0, period = 1;
     for (i64 sidx = a.seg_begin + sl; sidx < a.seg_end; sidx += slices) {
       const u32 row0 = segs[sidx].row0;
       const u32 first = segs[sidx].first;
       const u32 npaths = segs[sidx].n;
-      if (a.prune && !(a.ablate & 8) && ++since >= period) {
-        exchange();
-        since = 0;
-        period = period < kIeRefresh ? period * 2 : kIeRefresh;
-      }
-
       // ---- per-path metadata of the whole segment in a few coalesced loads: lane t <-> joined path first + t.
       // The path loop below takes everything out of these registers with v_readlane.
       const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
@@ -252,9 +180,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
       u32 ttv[M];
 #pragma unroll
       for (int h = 0; h < M; h++) ttv[h] = a.tot[(u64)qv * M + h];
-      u32 lhv = 0u;
-      if constexpr (M == 1)
-        if (a.prune) lhv = a.ladder[lad_base + ttv[0]];
       u32 lv[M][8];      // the first 8 entries of every list (lists are padded to 8: most lists end there)
 #pragma unroll
       for (int h = 0; h < M; h++) {
@@ -304,12 +229,12 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
           // the 8 mask rows every list starts with (zero rows past its real end) ...
           u32 offs[8], y[8];
 #pragma unroll
-          for (int j = 0; j < 8; j++) offs[j] = (a.ablate & 2) ? a.zoff : rdlane(lv[h][j], t);
+          for (int j = 0; j < 8; j++) offs[j] = rdlane(lv[h][j], t);
 #pragma unroll
           for (int j = 0; j < 8; j++) y[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
           // ... and the planes of the row the join adds, when the list is the overlap with paths0
           u32 Z[L];
-          if (overlap && !(a.ablate & 1)) {
+          if (overlap) {
             load_planes(Z, a.planesz, rdlane(zunit[h], t), a.gz);
           } else {
 #pragma unroll
@@ -362,23 +287,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
           }
         }
         if (q < a.score_begin || q >= a.score_end) continue;   // planes only: the path belongs to another shard
-        if (a.ablate & 4) {   // diagnostics: keep the counters alive, skip the epilogue
-          if (C[0][0] == 0x12345678u && C[0][L - 1] == 0x9abcdef0u) scr[0] = 1u;
-          continue;
-        }
         if constexpr (M == 1) {
-          if (a.prune) {
-            const u32 lh = rdlane(lhv, t);
-            const u32 m = outside(C[0], lh & 0xffffu, lh >> 16);
-            const u64 lanes = __builtin_amdgcn_ballot_w64(m != 0u);
-            if (lanes == 0ull) continue;
-            n_slow++;
-            // a handful of permutations: one by one; many (thresholds still low): transpose all 2048 counts
-            if (__builtin_popcountll(lanes) <= 8 && __builtin_amdgcn_ballot_w64((m & (m - 1u)) != 0u && ((m & (m - 1u)) & ((m & (m - 1u)) - 1u)) != 0u) == 0ull) {
-              finish_some(C[0], rdlane(ttv[0], t), m);
-              continue;
-            }
-          }
           finish_m1(C[0], rdlane(ttv[0], t));
         } else {
           finish_m2(C[0], C[M - 1], rdlane(ttv[0], t), rdlane(ttv[M - 1], t));
@@ -387,7 +296,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
     }
   }
   flush();
-  if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -878,54 +786,6 @@ hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipSt
 }
 
 // ------------------------------------------------------------------------------------------------
-// inspector: per joined path (and half) the list the kernel streams -- the bits of the reduced row z that are
-// clear in the paths0 row (mode 0, delta) or set in it (mode 1, overlap); the mode sits in bit 0 of doff
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ie_fill(const u32* p0, int S32, int W32p, int M, const u32* row0, const u32* rowz,
-                                                 i64 count, const u64* loffz, const u32* lidxz, const u64* doff,
-                                                 u32 zoff, u32* dlist) {
-  const int lane = threadIdx.x & 63;
-  const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
-  for (i64 w = wave; w < count * M; w += nwaves) {
-    const i64 i = w / M;
-    const int h = (int)(w % M);
-    const u32* r0 = p0 + (size_t)row0[i] * S32 + (size_t)h * W32p;
-    const u32 rzraw = rowz[i];
-    const u32 rz = rzraw & 0x7fffffffu;
-    const int hz = (M == 2 && (rzraw >> 31)) ? 1 - h : h;
-    const u64 li = (u64)rz * M + hz;
-    const u64 b1 = loffz[li], e1 = loffz[li + 1];
-    const u64 o0 = doff[w];
-    const bool want_set = (o0 & 1u) != 0u;
-    u64 out = o0 & ~(u64)3;
-    const u64 out_end = doff[w + 1] & ~(u64)3;
-    for (u64 p = b1; p < e1; p += 64) {
-      const u32 e = (p + lane < e1) ? lidxz[p + lane] : zoff;
-      const u32 idx = e >> 8;
-      bool keep = (e != zoff);
-      const u32 w0 = keep ? r0[idx >> 5] : 0u;
-      keep = keep && ((((w0 >> (idx & 31u)) & 1u) != 0u) == want_set);
-      const u64 m = __ballot(keep);
-      const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-      if (keep) dlist[out + before] = e;
-      out += (u64)__builtin_popcountll(m);
-    }
-    if (out + lane < out_end) dlist[out + lane] = zoff;
-  }
-}
-
-hipError_t launch_ie_fill(const uint32_t* p0, int S32, int W32p, int method, const uint32_t* row0, const uint32_t* rowz,
-                          int64_t count, const uint64_t* loffz, const uint32_t* lidxz, const uint64_t* doff, uint32_t zoff,
-                          uint32_t* dlist, hipStream_t stream) {
-  if (count == 0) return hipSuccess;
-  const i64 blocks = (count * method + 3) / 4;
-  hipLaunchKernelGGL(k_ie_fill, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream, p0, S32, W32p,
-                     method, row0, rowz, count, loffz, lidxz, doff, zoff, dlist);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
 // inspector of the IE form, one pass: real-label statistics and observed score of every joined path (what k_stats
 // does, methods.h:73-93), the kept row, the check of the reduced operand, the choice delta / overlap list and the
 // list itself.  One wave per joined path.
@@ -1048,7 +908,7 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
     }
     if (active && sl == 0) {
       if constexpr (M == 1) {
-        const double s = (a.ablate & 2) ? 1.0 : a.dvt[(size_t)sp_diag_offset(tot[0]) + inc[0]];   // vt[cases][ctrls], methods.h:90
+        const double s = a.dvt[(size_t)sp_diag_offset(tot[0]) + inc[0]];   // vt[cases][ctrls], methods.h:90
         a.key[i] = ie_score_key(s);
         a.tot[i] = tot[0];
         a.cases[i] = inc[0];
@@ -1067,7 +927,6 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
     }
 
     // ---- pass 2: the lists.  Entry = patient << 8 (byte offset of the patient's row in a mask tile) ----
-    if (a.ablate & 1) continue;
 #pragma unroll
     for (int h = 0; h < M; h++) {
       const u64 d = (u64)i * M + h;
@@ -1122,10 +981,8 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
           const u32 b = (u32)__builtin_ctzll(w);
           w &= w - 1;
           const u32 e = (k * 64u + b) << 8;
-          if (!(a.ablate & 4)) {
-            if (pos < 8u) { if (active) slot[pos] = e; }
-            else if (ov_ok) over[pos - 8u] = e;
-          }
+          if (pos < 8u) { if (active) slot[pos] = e; }
+          else if (ov_ok) over[pos - 8u] = e;
           pos++;
         }
       };
@@ -1135,11 +992,11 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
       } else {
         for (int it = 0; it < nit; it++) emit(it);
       }
-      for (u32 p = len[h] + (u32)sl; p < len8 && !(a.ablate & 8); p += 16) {   // padding: the all-zero mask row
+      for (u32 p = len[h] + (u32)sl; p < len8; p += 16) {   // padding: the all-zero mask row
         if (p < 8u) { if (active) slot[p] = a.zoff; }
         else if (ov_ok) over[p - 8u] = a.zoff;
       }
-      if (active && sl == 0 && !(a.ablate & 16)) {
+      if (active && sl == 0) {
         a.linfo[d] = len8 | mode[h];
         a.lover[d] = ovb;
       }

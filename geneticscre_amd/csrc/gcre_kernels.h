@@ -119,20 +119,15 @@ struct IeArgs {
   uint32_t score_begin, score_end;   // joined paths of the launch outside [begin, end) only produce planes
   int nkt, waves_per_xcd, K;
   int g0, gz, go;            // plane groups (4 planes each) of the three plane arrays
-  int prune;                 // general kernel, method 1: test counts against the ladder before the table lookup
   int lad_mode;              // method-1 kernel: 0 thresholds from the running maxima, 1 look nothing up, 2 look everything up
   int ladder_stride;         // = number of table diagonals
   uint32_t mt_rows, zoff;
-  int ablate;                // diagnostics only (GCRE_IE_ABLATE): wrong results, shows where the time goes
 };
 hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general, hipStream_t stream);
 int ie_max_waves_per_cu(int method, int planes, int gz, bool out);
 hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, const uint64_t* loff, const uint32_t* lidx,
                                int64_t nrowhalves, int groups, uint32_t* planes, hipStream_t stream);
 hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipStream_t stream);
-hipError_t launch_ie_fill(const uint32_t* p0, int S32, int W32p, int method, const uint32_t* row0, const uint32_t* rowz,
-                          int64_t count, const uint64_t* loffz, const uint32_t* lidxz, const uint64_t* doff, uint32_t zoff,
-                          uint32_t* dlist, hipStream_t stream);
 // exclusive prefix sum of n u32 counts into n+1 u64 offsets; the low 2 bits of a count do not add, they are copied
 // into the low bits of its offset (list lengths are multiples of 4, bit 0 carries the IE list mode) (scratch: >= (n+1023)/1024 + 1 u64)
 hipError_t launch_scan_u32_u64(const uint32_t* cnt, int64_t n, uint64_t* off, uint64_t* scratch, hipStream_t stream);
@@ -182,7 +177,6 @@ struct StatsArgs {
   // k_stats_ie only: the lists themselves, written in the same pass (no scan, no fill kernel).  List d = path*M + half
   // has its first 8 entries in slot[d*8 .. d*8+8) and the rest, when it is longer, in over[lover[d] ..); both padded
   // with `zoff` to a multiple of 8.  linfo[d] = padded length | mode (bit 0: 1 = overlap list).
-  int ablate;                  // diagnostics only (GCRE_STATS_ABLATE)
   const uint64_t* excess;      // hinted joins: [ranges][S] union of paths1 & ~reduced over each uid range (k_range_union), or nullptr
   const int32_t* range_of;     // uid (row of paths0) -> its range
   uint32_t* linfo;
