@@ -431,13 +431,10 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       const u32 zunit = ((u32)kt * (u32)a.rowsz + (a.rowz[qv] & 0x7fffffffu)) * (u32)a.gz;   // 1 KB units into planesz
       const u32 totv = a.tot[qv];
       const u32 lhv = a.ladder[lad_base + totv];
-      u32 lv[8];          // the first 8 entries of every list (lists are padded to 8: most lists end there)
-      {
-        const u32x4* lp = (const u32x4*)(a.dlist + (u64)qv * 8u);
-        const u32x4 e0 = lp[0], e1 = lp[1];
-        lv[0] = e0.x; lv[1] = e0.y; lv[2] = e0.z; lv[3] = e0.w;
-        lv[4] = e1.x; lv[5] = e1.y; lv[6] = e1.z; lv[7] = e1.w;
-      }
+      // the first 8 entries of every list (lists are padded to 8: most lists end there) are wave-uniform: they come
+      // through the scalar cache, one s_load_dwordx8 per path, fetched one path ahead of the loads that use them
+      typedef u32 __attribute__((ext_vector_type(8))) u32x8;
+      const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 8u);
       // ---- base counters: the planes of paths0[row0] ----
       u32 B[L];
       {
@@ -455,10 +452,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       // ---- the joined paths of the segment, software-pipelined one path ahead: the 8 mask rows and the planes of
       // path t+1 are in flight while path t is computed.  Loads are issued unconditionally (the last path is simply
       // requested twice) so that the compiler's counters let the older loads retire without draining the younger.
-      auto issue = [&](u32 t2, u32 (&yy)[8], u32 (&ZZ)[4 * GZ]) {
-        u32 offs[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) offs[j] = rdlane(lv[j], t2);
+      auto issue = [&](u32 t2, const u32x8 offs, u32 (&yy)[8], u32 (&ZZ)[4 * GZ]) {
 #pragma unroll
         for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
         const u32x4* src = (const u32x4*)(a.planesz + (u64)rdlane(zunit, t2) * 256u) + lane;
@@ -521,7 +515,6 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
           for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
           const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + rdlane(lovv, t));
           for (u32 p = 0u; p + 8u < len; p += 8u) {
-            typedef u32 __attribute__((ext_vector_type(8))) u32x8;
             const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
             u32 yy[8], s4[4];
 #pragma unroll
@@ -612,12 +605,16 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
 
       u32 yA[8], yB[8], ZA[4 * GZ], ZB[4 * GZ];
       const u32 last = npaths - 1u;
-      issue(0u, yA, ZA);
+      auto at = [&](u32 t2) -> u32 { return t2 < last ? t2 : last; };
+      u32x8 oA = slots[0], oB = slots[at(1u)];
+      issue(0u, oA, yA, ZA);
       for (u32 t = 0; t < npaths; t += 2) {
-        issue(t + 1 < last ? t + 1 : last, yB, ZB);
+        issue(at(t + 1), oB, yB, ZB);
+        oA = slots[at(t + 2)];
         compute(t, yA, ZA);
         if (t + 1 < npaths) {
-          issue(t + 2 < last ? t + 2 : last, yA, ZA);
+          issue(at(t + 2), oA, yA, ZA);
+          oB = slots[at(t + 3)];
           compute(t + 1, yB, ZB);
         }
       }
