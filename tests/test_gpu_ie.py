@@ -212,3 +212,22 @@ def test_perm_window_arguments():
         with pytest.raises(api.GcreError):
             ex.set_perm_window(*bad)
     ex.close()
+
+
+@pytest.mark.parametrize("method,density,n", [("method1", 0.45, 1600), ("method2", 0.45, 1600), ("method1", 0.3, 9000),
+                                               ("method2", 0.3, 9000), ("method1", 0.02, 9000)])
+def test_wide_counters_and_dense_rows(method, density, n, monkeypatch):
+    """Every counter width of the IE kernels: dense rows over 1,600 patients (12 planes, gene planes of 3 groups, long
+    overlap and delta lists through the overflow area) and over 9,000 patients (16 planes, up to 4 groups), plus rare
+    variants over 9,000 patients (141 words per row: the inspector's 10-pass row loop)."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    nc = n // 2 - 37
+    p = make_problem(24, 55, nc, n - nc, 130, 4, method=method, top_k=9, seed=21, threshold=0.9,
+                     table=small_table(nc, n - nc, 4))
+    rng = np.random.default_rng(6)
+    p.data1 = (rng.random(p.data1.shape) < density).astype(np.int32)
+    p.data2 = p.data1[p.levels.uids["1b"].src]
+    got = api.process_paths(p)
+    want = oracle.process_paths(p, order="canonical")
+    check_levels(got, want, range(1, 5))
+    assert got["profile"]["ie_launches"] >= 5 and got["profile"]["ie_hinted_joins"] == 5
