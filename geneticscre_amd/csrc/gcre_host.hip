@@ -59,6 +59,18 @@ inline double key_to_score(uint64_t k) {
 
 inline size_t tri(size_t t) { return t * (t + 1) / 2; }
 
+// GCRE_HOST_TIMING=1: wall time of the host-side steps around the kernels (stderr)
+struct HostTimer {
+  const char* what;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTimer(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
+  ~HostTimer() {
+    static const bool on = std::getenv("GCRE_HOST_TIMING") != nullptr;
+    if (on) std::fprintf(stderr, "[host] %-28s %8.2f ms\n", what,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+
 }  // namespace
 
 struct gcre_ctx {
@@ -98,6 +110,11 @@ struct gcre_ctx {
   DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz, d_ie_scratch, d_linfo, d_lover, d_dover;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
 
+  // count-plane buffers of freed path sets, kept for the next set that needs one (hipMalloc of tens of GB costs
+  // ~40 ms per GB on this platform, hipFree nothing)
+  struct PlaneBuf { uint32_t* p; size_t bytes; };
+  std::vector<PlaneBuf> plane_pool;
+
   gcre_profile prof{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_null, ev_stats;
   std::vector<hipEvent_t> ev_pool;
@@ -116,6 +133,7 @@ struct gcre_pathset {
   // count planes for the inclusion-exclusion kernel: [tile][row*M+h][groups][64][4] dwords, valid for one mask epoch
   mutable uint32_t* d_planes = nullptr;
   mutable int plane_groups = 0;
+  mutable size_t planes_bytes = 0;   // capacity of d_planes
   mutable uint64_t planes_epoch = 0;
   mutable bool planes_valid = false;
 };
@@ -192,6 +210,7 @@ double drain_events(gcre_ctx* c, std::vector<std::pair<hipEvent_t, hipEvent_t>>&
 }
 
 gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
+  HostTimer ht("new_pathset");
   if (nrows < 0) {
     fail(c, GCRE_ERR_ARG, "negative path-set size");
     return nullptr;
@@ -206,7 +225,14 @@ gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
   ps->ctx = c;
   ps->nrows = nrows;
   const size_t bytes = (size_t)std::max<int64_t>(nrows, 1) * c->g.S * sizeof(uint64_t);
-  if (hipMalloc((void**)&ps->d_rows, bytes) != hipSuccess) {
+  hipError_t me = hipMalloc((void**)&ps->d_rows, bytes);
+  if (me != hipSuccess && !c->plane_pool.empty()) {   // pooled plane buffers are only a convenience
+    (void)hipGetLastError();
+    for (auto& pb : c->plane_pool) (void)hipFree(pb.p);
+    c->plane_pool.clear();
+    me = hipMalloc((void**)&ps->d_rows, bytes);
+  }
+  if (me != hipSuccess) {
     fail(c, GCRE_ERR_DEVICE, "hipMalloc failed for a path set of " + std::to_string(bytes) + " bytes");
     delete ps;
     return nullptr;
@@ -244,8 +270,23 @@ int build_transposed_masks(gcre_ctx* c) {
 }
 
 void drop_planes(const gcre_pathset* ps) {
-  if (ps->d_planes) (void)hipFree(ps->d_planes);
+  if (ps->d_planes) {
+    gcre_ctx* c = ps->ctx;
+    if (c) {
+      c->plane_pool.push_back({ps->d_planes, ps->planes_bytes});
+      if (c->plane_pool.size() > 8) {   // keep the eight largest
+        size_t small = 0;
+        for (size_t k = 1; k < c->plane_pool.size(); k++)
+          if (c->plane_pool[k].bytes < c->plane_pool[small].bytes) small = k;
+        (void)hipFree(c->plane_pool[small].p);
+        c->plane_pool.erase(c->plane_pool.begin() + (long)small);
+      }
+    } else {
+      (void)hipFree(ps->d_planes);
+    }
+  }
   ps->d_planes = nullptr;
+  ps->planes_bytes = 0;
   ps->plane_groups = 0;
   ps->planes_valid = false;
 }
@@ -264,6 +305,7 @@ void drop_lists(const gcre_pathset* ps) {
 // CSR bit lists of a path set (method 1: one list per row): offsets on the host by prefix sum, entries on the device
 int ensure_lists(gcre_ctx* c, const gcre_pathset* ps) {
   if (ps->d_loff) return GCRE_OK;
+  HostTimer ht("ensure_lists");
   const Geometry& g = c->g;
   // method 2: every row is two half-rows (+)/(-) of W32p dwords, stored back to back -> 2*nrows lists
   const int64_t n = ps->nrows * g.method;
@@ -329,17 +371,35 @@ bool planes_fit(size_t bytes) {
 
 // allocate (not fill) the plane array of a set; false when it does not fit
 bool alloc_planes(gcre_ctx* c, const gcre_pathset* ps, int groups) {
-  if (ps->d_planes && ps->plane_groups == groups) {
+  HostTimer ht("alloc_planes");
+  const size_t bytes = plane_bytes(c, ps->nrows, groups);
+  if (ps->d_planes && ps->planes_bytes >= bytes) {   // its own buffer is large enough (another window, other groups)
+    ps->plane_groups = groups;
     ps->planes_valid = false;
     return true;
   }
   drop_planes(ps);
-  const size_t bytes = plane_bytes(c, ps->nrows, groups);
-  if (!planes_fit(bytes)) return false;
-  if (hipMalloc((void**)&ps->d_planes, bytes) != hipSuccess) {
-    ps->d_planes = nullptr;
-    (void)hipGetLastError();
-    return false;
+  // smallest pooled buffer that is large enough
+  int best = -1;
+  for (size_t k = 0; k < c->plane_pool.size(); k++)
+    if (c->plane_pool[k].bytes >= bytes && (best < 0 || c->plane_pool[k].bytes < c->plane_pool[(size_t)best].bytes)) best = (int)k;
+  if (best >= 0) {
+    ps->d_planes = c->plane_pool[(size_t)best].p;
+    ps->planes_bytes = c->plane_pool[(size_t)best].bytes;
+    c->plane_pool.erase(c->plane_pool.begin() + best);
+  } else {
+    if (!planes_fit(bytes)) {
+      // make room: pooled buffers that are too small are of no use to anybody
+      for (auto& pb : c->plane_pool) (void)hipFree(pb.p);
+      c->plane_pool.clear();
+      if (!planes_fit(bytes)) return false;
+    }
+    if (hipMalloc((void**)&ps->d_planes, bytes) != hipSuccess) {
+      ps->d_planes = nullptr;
+      (void)hipGetLastError();
+      return false;
+    }
+    ps->planes_bytes = bytes;
   }
   ps->plane_groups = groups;
   return true;
@@ -372,6 +432,7 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
       *nsegs = sc.nsegs;
       return GCRE_OK;
     }
+  HostTimer ht("sparse_segments");
   std::vector<SparseSeg> segs;
   const auto& pi = u.h_path_idx;
   const int64_t end = first + count;
@@ -385,9 +446,24 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
   // Segments that join the same paths1 rows (all uids with the same pivot gene share `location`) run next to each
   // other: the waves of an XCD walk a contiguous window of this table, so the planes of those rows stay in its L2.
   // Any order gives the same maxima.
-  std::stable_sort(segs.begin(), segs.end(), [&](const SparseSeg& x, const SparseSeg& y) {
-    return u.h_location[x.row0] < u.h_location[y.row0];
-  });
+  {
+    // a stable counting sort on `location` (rows of paths1: dense keys) -- a comparison sort of millions of
+    // segments is a noticeable part of a one-shot gcre_process_paths call
+    int64_t max_loc = 0;
+    for (const SparseSeg& sg : segs) max_loc = std::max(max_loc, u.h_location[sg.row0]);
+    if (!segs.empty() && max_loc < (int64_t)64 * (int64_t)segs.size() + 1024) {
+      std::vector<uint32_t> start((size_t)max_loc + 2, 0);
+      for (const SparseSeg& sg : segs) start[(size_t)u.h_location[sg.row0] + 1]++;
+      for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+      std::vector<SparseSeg> sorted(segs.size());
+      for (const SparseSeg& sg : segs) sorted[start[(size_t)u.h_location[sg.row0]]++] = sg;
+      segs.swap(sorted);
+    } else {
+      std::stable_sort(segs.begin(), segs.end(), [&](const SparseSeg& x, const SparseSeg& y) {
+        return u.h_location[x.row0] < u.h_location[y.row0];
+      });
+    }
+  }
   SparseSeg* d = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d, std::max<size_t>(segs.size(), 1) * sizeof(SparseSeg)));
   if (!segs.empty())
@@ -495,6 +571,7 @@ void free_uids(gcre_uids* u) {
 // validation that does not need the path sets (join_base.cpp:198-200 checks the rest in run_join)
 gcre_uids* make_uids(gcre_ctx* c, int path_length, const int32_t* uid_count, const int64_t* uid_location,
                      int64_t n_uids, const int32_t* signs, int64_t n_signs) {
+  HostTimer ht("make_uids");
   auto* u = new gcre_uids{};
   u->ctx = c;
   u->path_length = path_length;
@@ -540,6 +617,7 @@ gcre_uids* make_uids(gcre_ctx* c, int path_length, const int32_t* uid_count, con
 // distinct (location, count) ranges of a join index, uid -> range (see k_range_union)
 int ensure_ranges(gcre_ctx* c, const gcre_uids& u) {
   if (u.n_ranges >= 0) return GCRE_OK;
+  HostTimer ht("ensure_ranges");
   const auto& pi = u.h_path_idx;
   std::vector<int32_t> range_of((size_t)std::max<int64_t>(u.n_uids, 1), 0);
   std::vector<int64_t> loc;
@@ -616,10 +694,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   if (keep) {   // its rows are about to be rewritten: lists go, the plane buffer stays allocated for the new rows
     uint32_t* planes = jp.res->d_planes;
     const int groups = jp.res->plane_groups;
+    const size_t pbytes = jp.res->planes_bytes;
     jp.res->d_planes = nullptr;
     drop_lists(jp.res);
     jp.res->d_planes = planes;
     jp.res->plane_groups = groups;
+    jp.res->planes_bytes = pbytes;
   }
   if (g.method == 2 && P > 0) {
     // need_flip reads signs[idx] and/or signs[loc] (gcre.h:71-81); the reference would read out of bounds
@@ -1257,6 +1337,8 @@ void gcre_destroy(gcre_ctx* c) {
   c->d_linfo.release();
   c->d_lover.release();
   c->d_dover.release();
+  for (auto& pb : c->plane_pool) (void)hipFree(pb.p);
+  c->plane_pool.clear();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1273,6 +1355,7 @@ int gcre_width_ul(const gcre_ctx* c) { return c ? c->g.W : GCRE_ERR_ARG; }
 int gcre_vlen(const gcre_ctx* c) { return c ? c->g.W * c->g.method : GCRE_ERR_ARG; }
 
 int gcre_set_value_table(gcre_ctx* c, const double* table, int nrow, int ncol, int col_major) {
+  HostTimer ht("set_value_table");
   if (!c || (!table && nrow > 0 && ncol > 0) || nrow < 0 || ncol < 0) return fail(c, GCRE_ERR_ARG, "bad value table");
   (void)hipSetDevice(c->device);
   const Geometry& g = c->g;
@@ -1558,6 +1641,7 @@ int gcre_pathset_read(gcre_ctx* c, const gcre_pathset* ps, uint64_t* out_rows) {
 }
 
 void gcre_pathset_free(gcre_pathset* ps) {
+  HostTimer ht("pathset_free");
   if (!ps) return;
   if (ps->ctx) {
     (void)hipSetDevice(ps->ctx->device);
@@ -1711,7 +1795,10 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
 
   gcre_pathset *parsed1 = nullptr, *parsed2 = nullptr, *paths1 = nullptr, *paths2 = nullptr, *paths3 = nullptr;
   std::vector<gcre_pathset*> temps;
+  gcre_uids** uids_to_free = nullptr;
   auto cleanup = [&]() {
+    if (uids_to_free)
+      for (int i = 0; i < 6; i++) { free_uids(uids_to_free[i]); uids_to_free[i] = nullptr; }
     for (auto* p : temps) gcre_pathset_free(p);
     for (auto* p : {parsed1, parsed2, paths1, paths2, paths3}) gcre_pathset_free(p);
   };
@@ -1720,21 +1807,27 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     for (int64_t i = 0; i < lv.n_uids; i++) t += std::max(lv.uid_count[i], 0);
     return t;
   };
-  // red/red_index: what the join really adds to paths0 (gcre_uids_set_reduced) -- checked per join, never trusted
-  auto join = [&](int plen, const gcre_level& lv, const gcre_pathset* p0, const gcre_pathset* p1, gcre_pathset* res,
+  // red/red_index: what the join really adds to paths0 (gcre_uids_set_reduced) -- checked per join, never trusted.
+  // The join index of a level is uploaded once and serves every permutation window.
+  gcre_uids* level_uids[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uids_to_free = level_uids;
+  auto join = [&](int plen, int lvi, const gcre_pathset* p0, const gcre_pathset* p1, gcre_pathset* res,
                   gcre_result* o, const gcre_pathset* red = nullptr, const int32_t* red_index = nullptr,
                   int64_t n_red = 0) -> int {
-    gcre_uids* u = make_uids(c, plen, lv.uid_count, lv.uid_location, lv.n_uids, lv.signs, lv.n_signs);
-    if (!u) return c->last_code;
-    if (red && red_index && n_red >= p1->nrows) {
+    const gcre_level& lv = in->level[lvi];
+    gcre_uids*& u = level_uids[lvi];
+    if (!u) {
+      u = make_uids(c, plen, lv.uid_count, lv.uid_location, lv.n_uids, lv.signs, lv.n_signs);
+      if (!u) return c->last_code;
+    }
+    if (!u->red && red && red_index && n_red >= p1->nrows) {   // once: the operand outlives the windows
       bool in_range = true;
       for (int64_t i = 0; i < n_red && in_range; i++) in_range = (int64_t)((uint32_t)red_index[i] & 0x7fffffffu) < red->nrows;
-      if (in_range && gcre_uids_set_reduced(u, red, red_index, n_red) != GCRE_OK) { free_uids(u); return c->last_code; }
+      if (in_range && gcre_uids_set_reduced(u, red, red_index, n_red) != GCRE_OK) return c->last_code;
     }
     JoinPlan jp{u, p0, p1, res, false, 0, 0, nullptr};
     gcre_result tmp;
     int r = run_join(c, jp, &tmp);
-    free_uids(u);
     if (r != GCRE_OK) { gcre_result_free(&tmp); return r; }
     add_prof();
     if (o) *o = tmp; else gcre_result_free(&tmp);
@@ -1758,7 +1851,24 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
   for (int lv = 0; lv < 4 && lv <= L; lv++)
     if (lv != 1) kept_rows += total_paths(in->level[lv]);
   const int Kall = c->g.K;
-  const int win = std::max(1, gcre_plan_perm_window(c, kept_rows));
+  int win = std::max(1, gcre_plan_perm_window(c, kept_rows));
+  if (Kall > kSparseTile && sparse_enabled(c)) {
+    // A context without a pooled plane buffer of the full size (the R shim makes a fresh context per call, as the
+    // reference does) has to hipMalloc the planes: ~40 ms per GB here, 3 KB per kept row and tile.  Against ~25 ms of
+    // repeated inspector work per extra window, few tiles per window win: w* = sqrt(25 ms * tiles / (ms per tile)).
+    int64_t biggest = 0;
+    for (int lv = 0; lv < 4 && lv <= L; lv++)
+      if (lv != 1) biggest = std::max(biggest, total_paths(in->level[lv]));
+    const double ms_per_tile = (double)biggest * c->g.method * 3072.0 / 1e9 * 40.0;
+    const int nkt_all = (Kall + kSparseTile - 1) / kSparseTile;
+    const size_t full_bytes = (size_t)biggest * c->g.method * 3072 * (size_t)((win + kSparseTile - 1) / kSparseTile);
+    bool pooled = false;
+    for (const auto& pb : c->plane_pool) pooled = pooled || pb.bytes >= full_bytes;
+    if (ms_per_tile > 1.0 && !pooled) {
+      const int w = std::max(1, (int)std::sqrt(25.0 * nkt_all / ms_per_tile));
+      win = std::min(win, w * kSparseTile);
+    }
+  }
   std::vector<float> null_all[5];
   for (int k0 = 0; k0 < std::max(Kall, 1); k0 += win) {
     const bool first_window = k0 == 0;
@@ -1787,7 +1897,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       gcre_pathset* input1 = gcre_pathset_select(c, parsed1, in->data_inds[0], in->n_data_inds[0]);
       PP_REQUIRE(input1);
       temps.push_back(input1);
-      PP_TRY(join(1, in->level[0], zero1, input1, paths1, nullptr, parsed1, in->data_inds[0], in->n_data_inds[0]));   // result discarded, wrapper.cpp:233
+      PP_TRY(join(1, 0, zero1, input1, paths1, nullptr, parsed1, in->data_inds[0], in->n_data_inds[0]));   // result discarded, wrapper.cpp:233
 
       if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 1);
       gcre_pathset* zero2 = gcre_pathset_zeros(c, in->n_data_inds[1]);
@@ -1798,7 +1908,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       gcre_pathset* input2 = gcre_pathset_select(c, parsed2, in->data_inds[1], in->n_data_inds[1]);
       PP_REQUIRE(input2);
       temps.push_back(input2);
-      PP_TRY(join(1, in->level[1], zero2, input2, nullptr, &out_w[0], parsed2, in->data_inds[1], in->n_data_inds[1]));
+      PP_TRY(join(1, 1, zero2, input2, nullptr, &out_w[0], parsed2, in->data_inds[1], in->n_data_inds[1]));
     }
     if (L >= 2) {   // wrapper.cpp:246-253
       if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 2);
@@ -1808,7 +1918,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
       PP_REQUIRE(input);
       temps.push_back(input);
-      PP_TRY(join(2, in->level[2], paths1, input, paths2, &out_w[1], parsed1, in->data_inds[3], in->n_data_inds[3]));
+      PP_TRY(join(2, 2, paths1, input, paths2, &out_w[1], parsed1, in->data_inds[3], in->n_data_inds[3]));
     }
     if (L >= 3) {   // wrapper.cpp:255-262
       if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 3);
@@ -1817,7 +1927,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
       PP_REQUIRE(input);
       temps.push_back(input);
-      PP_TRY(join(3, in->level[3], paths2, input, paths3, &out_w[2], parsed1, in->data_inds[3], in->n_data_inds[3]));
+      PP_TRY(join(3, 3, paths2, input, paths3, &out_w[2], parsed1, in->data_inds[3], in->n_data_inds[3]));
     }
     if (L >= 4) {   // wrapper.cpp:264-269
       if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 4);
@@ -1828,7 +1938,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
         const bool neg = c->g.method == 2 && i < in->level[2].n_signs && in->level[2].signs[i] != 1;
         added[(size_t)i] = (int32_t)((uint32_t)in->data_inds[3][i] | (neg ? 0x80000000u : 0u));
       }
-      PP_TRY(join(4, in->level[4], paths3, paths2, nullptr, &out_w[3], parsed1, added.data(), (int64_t)added.size()));
+      PP_TRY(join(4, 4, paths3, paths2, nullptr, &out_w[3], parsed1, added.data(), (int64_t)added.size()));
     }
     if (L >= 5) {   // wrapper.cpp:271-276
       if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 5);
@@ -1844,7 +1954,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
             second.push_back((int32_t)((uint32_t)(l3.uid_location[i] + t) | (neg ? 0x80000000u : 0u)));
         }
       }
-      PP_TRY(join(5, in->level[5], paths3, paths3, nullptr, &out_w[4], paths2, second.data(), (int64_t)second.size()));
+      PP_TRY(join(5, 5, paths3, paths3, nullptr, &out_w[4], paths2, second.data(), (int64_t)second.size()));
     }
     fold();
     for (auto* p : temps) gcre_pathset_free(p);   // this window's operand copies
