@@ -67,6 +67,40 @@ hipError_t launch_generate_masks(uint64_t seed, int K, int n, int n_strata, cons
   return hipGetLastError();
 }
 
+// The caller's value table (nrow x ncol doubles, row- or column-major) -> the device's diagonal-major triangles:
+// dvt[t(t+1)/2 + i] = table[i][t-i], -1 outside the table or beyond n patients (the reference pads its (n+1)^2 copy
+// with -1, join_base.cpp:67-78); t32 = the same cell rounded to f32 with everything that can never win clamped to +0
+// (method 1, methods.h:96-103); dmax = max(table[i][t-i], table[t-i][i]) with std::max semantics (method 2,
+// compute_value_table_max, methods.h:110-118).  One block row per diagonal.
+__global__ __launch_bounds__(256) void k_table_to_diag(const double* table, int nrow, int ncol, int col_major, int n, int TD,
+                                                       double* dvt, float* t32, double* dmax) {
+  const int t = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= TD || i > t) return;
+  auto VT = [&](int r, int q) -> double {
+    if (r > n || q > n || r >= nrow || q >= ncol) return -1.0;
+    return col_major ? table[(size_t)q * nrow + r] : table[(size_t)r * ncol + q];
+  };
+  const size_t at = ((size_t)t * ((size_t)t + 1)) / 2 + (size_t)i;
+  const double a = VT(i, t - i);
+  dvt[at] = a;
+  if (t32) {
+    const float f = (float)a;
+    t32[at] = (f > 0.0f) ? f : 0.0f;
+  }
+  if (dmax) {
+    const double b = VT(t - i, i);
+    dmax[at] = (a < b) ? b : a;
+  }
+}
+
+hipError_t launch_table_to_diag(const double* table, int nrow, int ncol, int col_major, int n, int TD, double* dvt,
+                                float* t32, double* dmax, hipStream_t stream) {
+  const dim3 grid((unsigned)((TD + 255) / 256), (unsigned)TD);
+  hipLaunchKernelGGL(k_table_to_diag, grid, dim3(256), 0, stream, table, nrow, ncol, col_major, n, TD, dvt, t32, dmax);
+  return hipGetLastError();
+}
+
 }  // namespace gcre
 
 namespace {

@@ -1360,51 +1360,29 @@ int gcre_set_value_table(gcre_ctx* c, const double* table, int nrow, int ncol, i
   (void)hipSetDevice(c->device);
   const Geometry& g = c->g;
   const int n = g.n;
-  // the reference pads the table to (n+1)x(n+1) with -1 (join_base.cpp:67-78); the device keeps it
-  // diagonal-major and also covers carrier counts up to the padded word width with -1
-  auto VT = [&](int r, int q) -> double {
-    if (r > n || q > n || r >= nrow || q >= ncol) return -1.0;
-    return col_major ? table[(size_t)q * nrow + r] : table[(size_t)r * ncol + q];
-  };
+  // the reference pads the table to (n+1)x(n+1) with -1 (join_base.cpp:67-78); the device keeps it diagonal-major
+  // (and covers carrier counts up to the padded word width with -1).  The repacking runs on the device: the raw table
+  // goes up as it is (k_table_to_diag, gcre_frontend.hip) -- on the host it is 10 s of cache misses at 50,000 patients.
   const size_t TD = (size_t)g.TD, NT = tri(TD);
-  std::vector<double> dvt(NT);
-  for (size_t t = 0; t < TD; t++) {
-    double* d = dvt.data() + tri(t);
-    for (size_t i = 0; i <= t; i++) d[i] = VT((int)i, (int)(t - i));
-  }
   for (void** p : {(void**)&c->d_dvt, (void**)&c->d_t32, (void**)&c->d_dmax})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
+  double* d_raw = nullptr;
+  const size_t raw = (size_t)nrow * (size_t)ncol;
   HIP_TRY(c, hipMalloc((void**)&c->d_dvt, NT * 8));
-  HIP_TRY(c, hipMemcpy(c->d_dvt, dvt.data(), NT * 8, hipMemcpyHostToDevice));
-  if (g.method == 1) {
-    // null lookups of method 1 only ever feed "if (p > cur) cur = (float)p" with cur starting at 0
-    // (methods.h:96-103): pre-round to f32 and clamp everything that can never win to +0
-    std::vector<float> t32(NT);
-    for (size_t i = 0; i < NT; i++) {
-      const float f = (float)dvt[i];
-      t32[i] = (f > 0.0f) ? f : 0.0f;
-    }
-    HIP_TRY(c, hipMalloc((void**)&c->d_t32, NT * 4));
-    HIP_TRY(c, hipMemcpy(c->d_t32, t32.data(), NT * 4, hipMemcpyHostToDevice));
-    if (TD <= 65536) {   // counts fit the 16-bit bounds of a ladder entry
-      if (!c->d_ladder) HIP_TRY(c, hipMalloc((void**)&c->d_ladder, (size_t)(kLadderLevels + 2) * TD * 4));
-      HIP_TRY(c, launch_build_ladder(c->d_t32, (int)TD, c->d_ladder, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-  } else {
-    // compute_value_table_max, methods.h:110-118: max(vt[r][c], vt[c][r]) with std::max semantics
-    std::vector<double> dmax(NT);
-    for (size_t t = 0; t < TD; t++) {
-      const double* d = dvt.data() + tri(t);
-      double* m = dmax.data() + tri(t);
-      for (size_t i = 0; i <= t; i++) {
-        const double a = d[i], b = d[t - i];
-        m[i] = (a < b) ? b : a;
-      }
-    }
-    HIP_TRY(c, hipMalloc((void**)&c->d_dmax, NT * 8));
-    HIP_TRY(c, hipMemcpy(c->d_dmax, dmax.data(), NT * 8, hipMemcpyHostToDevice));
+  if (g.method == 1) HIP_TRY(c, hipMalloc((void**)&c->d_t32, NT * 4));
+  else HIP_TRY(c, hipMalloc((void**)&c->d_dmax, NT * 8));
+  HIP_TRY(c, hipMalloc((void**)&d_raw, std::max<size_t>(raw, 1) * 8));
+  hipError_t e = hipSuccess;
+  if (raw) e = hipMemcpyAsync(d_raw, table, raw * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess)
+    e = launch_table_to_diag(d_raw, nrow, ncol, col_major, n, (int)TD, c->d_dvt, c->d_t32, c->d_dmax, c->stream);
+  if (e == hipSuccess && g.method == 1 && TD <= 65536) {   // counts fit the 16-bit bounds of a ladder entry
+    if (!c->d_ladder) e = hipMalloc((void**)&c->d_ladder, (size_t)(kLadderLevels + 2) * TD * 4);
+    if (e == hipSuccess) e = launch_build_ladder(c->d_t32, (int)TD, c->d_ladder, c->stream);
   }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_raw);
+  if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("set_value_table: ") + hipGetErrorString(e));
   c->have_table = true;
   return GCRE_OK;
 }

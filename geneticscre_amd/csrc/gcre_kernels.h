@@ -215,6 +215,8 @@ hipError_t launch_gather_winners(const uint32_t* sel, uint32_t nsel, const uint6
 hipError_t launch_generate_masks(uint64_t seed, int K, int n, int n_strata, const int32_t* stratum, const uint32_t* cases_in,
                                  const uint32_t* size_of, uint32_t* work, int W32p, int Kpad, uint32_t* masks,
                                  hipStream_t stream);
+hipError_t launch_table_to_diag(const double* table, int nrow, int ncol, int col_major, int n, int TD, double* dvt,
+                                float* t32, double* dmax, hipStream_t stream);
 hipError_t launch_fill_u32(uint32_t* p, int64_t n, uint32_t v, hipStream_t stream);
 hipError_t launch_max_merge(uint32_t* dst, const uint32_t* src, int n, hipStream_t stream);
 
