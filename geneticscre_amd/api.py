@@ -155,7 +155,7 @@ def load_library():
     lib.gcre_get_perm_mask.argtypes = [V, I, P]
     lib.gcre_uids_set_reduced.argtypes = [V, V, P, I64]
     lib.gcre_set_perm_window.argtypes = [V, I, I]
-    lib.gcre_plan_perm_window.argtypes = [V, I64]
+    lib.gcre_plan_perm_window.argtypes = [V, P, I]
     _LIB = lib
     return lib
 
@@ -357,9 +357,10 @@ class JoinExec:
         """Joins that follow score permutations [k0, k1) only (tile aligned); see gcre_set_perm_window."""
         self._check(self._lib.gcre_set_perm_window(self._h, int(k0), int(k1)))
 
-    def plan_perm_window(self, kept_rows: int) -> int:
-        """Permutations per window so that the count planes of ``kept_rows`` kept rows fit in device memory."""
-        w = self._lib.gcre_plan_perm_window(self._h, int(kept_rows))
+    def plan_perm_window(self, set_rows) -> int:
+        """Permutations per window so that the count planes of path sets with ``set_rows`` rows fit in device memory."""
+        rows = np.ascontiguousarray(np.atleast_1d(set_rows), dtype=np.int64)
+        w = self._lib.gcre_plan_perm_window(self._h, _ptr(rows), len(rows))
         if w < 0:
             self._check(w)
         return max(int(w), 1)
@@ -625,8 +626,8 @@ class ResidentPlan:
         and the concatenated null maxima."""
         K = self.problem.iterations
         if self._window is None:
-            kept = sum(ps.size for ps in self.kept.values()) + sum(ps.size for ps in self.parsed)
-            self._window = self.ex.plan_perm_window(kept) if K > 0 else 1
+            sets = [ps.size for ps in self.kept.values()] + [ps.size for ps in self.parsed]
+            self._window = self.ex.plan_perm_window(sets) if K > 0 else 1
         out: Dict[str, JoinResult] = {}
         nulls: Dict[str, list] = {}
         prof: Dict[str, float] = {}

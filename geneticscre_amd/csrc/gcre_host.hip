@@ -37,6 +37,21 @@ struct DevBuf {   // grow-only device scratch
     if (e == hipSuccess) cap = n;
     return e;
   }
+  // grow and keep the first `keep` elements
+  hipError_t grow_keep(size_t n, size_t keep, hipStream_t stream) {
+    if (n <= cap) return hipSuccess;
+    T* q = nullptr;
+    hipError_t e = hipMalloc((void**)&q, n * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+      e = hipMemcpyAsync(q, p, std::min(keep, cap) * sizeof(T), hipMemcpyDeviceToDevice, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = n;
+    return e;
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -114,16 +129,38 @@ struct gcre_ctx {
   // ~40 ms per GB on this platform, hipFree nothing)
   struct PlaneBuf { uint32_t* p; size_t bytes; };
   std::vector<PlaneBuf> plane_pool;
+  // live path sets by id: a recipe names its operands by id + version, never by pointer alone
+  std::unordered_map<uint64_t, const gcre_pathset*> live_sets;
+  uint64_t next_set_id = 0;
+  size_t planes_out_max = (size_t)8 << 30;   // kept sets (method 1) whose planes are larger keep a recipe only
 
   gcre_profile prof{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_null, ev_stats;
   std::vector<hipEvent_t> ev_pool;
 };
 
+// How a kept path set was made (method 1): row r = row row0[r] of set A | row rowz[r] of set Z, with the producing
+// join's list (the overlap of the two rows, or what Z adds) as its inspector left it.  Enough to rebuild the count
+// planes of any row for any permutation tile from the planes of A and Z, so the set's own planes (3 KB per row and
+// tile) need not be stored, written or read.  Independent of the masks.
+struct gcre_recipe {
+  uint64_t a_id = 0, z_id = 0;     // the operands: path-set ids and the versions of their rows
+  uint64_t a_ver = 0, z_ver = 0;
+  DevBuf<uint32_t> row0, rowz, linfo, lover, slot, over;
+  bool valid = false;
+  void release() {
+    for (auto* b : {&row0, &rowz, &linfo, &lover, &slot, &over}) b->release();
+    valid = false;
+  }
+};
+
 struct gcre_pathset {
   gcre_ctx* ctx;
   int64_t nrows;
   uint64_t* d_rows;   // max(nrows,1) x S words
+  uint64_t id = 0;                 // never reused inside a context
+  mutable uint64_t version = 0;    // bumped when the rows are rewritten
+  mutable gcre_recipe* rec = nullptr;
   // CSR bit lists for the sparse kernel, built on first use and dropped whenever the rows are rewritten
   mutable uint64_t* d_loff = nullptr;
   mutable uint32_t* d_lidx = nullptr;
@@ -224,6 +261,7 @@ gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
   auto* ps = new gcre_pathset{};
   ps->ctx = c;
   ps->nrows = nrows;
+  ps->id = ++c->next_set_id;
   const size_t bytes = (size_t)std::max<int64_t>(nrows, 1) * c->g.S * sizeof(uint64_t);
   hipError_t me = hipMalloc((void**)&ps->d_rows, bytes);
   if (me != hipSuccess && !c->plane_pool.empty()) {   // pooled plane buffers are only a convenience
@@ -245,6 +283,7 @@ gcre_pathset* new_pathset(gcre_ctx* c, int64_t nrows, bool zero) {
       return nullptr;
     }
   }
+  c->live_sets[ps->id] = ps;
   return ps;
 }
 
@@ -367,6 +406,17 @@ bool planes_fit(size_t bytes) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
   return bytes < free_b - free_b / 4;
+}
+
+// the operands of a set's recipe, if the recipe is complete and both operands still hold the rows it was made from
+bool recipe_operands(const gcre_ctx* c, const gcre_pathset* ps, const gcre_pathset** a, const gcre_pathset** z) {
+  if (!ps->rec || !ps->rec->valid) return false;
+  auto ia = c->live_sets.find(ps->rec->a_id), iz = c->live_sets.find(ps->rec->z_id);
+  if (ia == c->live_sets.end() || iz == c->live_sets.end()) return false;
+  if (ia->second->version != ps->rec->a_ver || iz->second->version != ps->rec->z_ver) return false;
+  *a = ia->second;
+  *z = iz->second;
+  return true;
 }
 
 // allocate (not fill) the plane array of a set; false when it does not fit
@@ -691,6 +741,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   const bool keep = jp.res != nullptr && jp.res->nrows != 0;   // keep_paths = paths_res.size != 0, join_base.cpp:217
   if (jp.res && jp.res->nrows != 0 && jp.res->nrows != P)
     return fail(c, GCRE_ERR_ASSERT, "assertion: paths_res.size != total paths");
+  if (keep) jp.res->version++;
   if (keep) {   // its rows are about to be rewritten: lists go, the plane buffer stays allocated for the new rows
     uint32_t* planes = jp.res->d_planes;
     const int groups = jp.res->plane_groups;
@@ -772,9 +823,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     const int nkt_sp = (g.K + kSparseTile - 1) / kSparseTile;
     bool hinted = want_ie && u.red && u.red->ctx == c && u.d_red_index && u.n_red_index > u.max_loc;
     const gcre_pathset* red = nullptr;
-    bool have_pz = false, have_p0 = false, res_planes = false, res_planes_ok = false;
+    bool have_pz = false, have_p0 = false, res_planes = false, res_planes_ok = false, use_rec = false;
+    const gcre_pathset *rec_a = nullptr, *rec_z = nullptr;
+    gcre_recipe* rcp = nullptr;   // the recipe this join leaves with the rows it keeps (method 1)
     uint32_t join_max_tot = 0;
-    bool ie_ran = false, ie_stat_pending = false;
+    bool ie_ran = false, ie_stat_pending = false, recipe_started = false, recipe_broken = false;
     auto collect_ie_stat = [&]() {
       if (!ie_stat_pending) return;
       uint32_t v = 0;
@@ -792,8 +845,18 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     const auto tp0 = std::chrono::steady_clock::now();
     if (want_ie) {
       if (int rc = prepare_z()) return rc;
-      if (int rc = ensure_planes(c, jp.p0)) return rc;     // no-op when a kept join left them behind
-      have_p0 = planes_current(c, jp.p0);
+      have_p0 = planes_current(c, jp.p0);                  // a kept join left them behind
+      if (!have_p0 && g.method == 1 && recipe_operands(c, jp.p0, &rec_a, &rec_z)) {
+        // ... or it left the recipe: the kernel rebuilds a row's planes from the planes of the recipe's operands
+        if (int rc = ensure_planes(c, rec_a)) return rc;
+        if (int rc = ensure_planes(c, rec_z)) return rc;
+        use_rec = planes_current(c, rec_a) && planes_current(c, rec_z);
+        have_p0 = use_rec;
+      }
+      if (!have_p0) {
+        if (int rc = ensure_planes(c, jp.p0)) return rc;   // from its bit lists
+        have_p0 = planes_current(c, jp.p0);
+      }
       if (!have_p0 || !have_pz) want_ie = false;   // the planes do not fit in device memory: delta streaming (gcre_sparse.hip)
       if (want_ie && hinted) {
         // the hint is checked without reading paths1 per joined path: once per distinct uid range here (the reduced
@@ -818,8 +881,35 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       if (want_ie && keep) {
         // carriers of a joined row <= carriers(paths0 row) + carriers(added row); <= padded patient count
         const uint32_t bound = std::min<uint32_t>((uint32_t)(64 * g.Wp), row_max(c, jp.p0) + row_max(c, red));
-        res_planes = alloc_planes(c, jp.res, plane_groups_for(bound));
-        res_planes_ok = res_planes;
+        const int out_groups = plane_groups_for(bound);
+        bool want_out = true;
+        if (g.method == 1) {
+          // the kept rows leave with the recipe of this join (its inspector output, 60 B per row).  Their planes are only
+          // written when they are small, or when the next join could not use the recipe (it needs stored planes of paths0)
+          if (!jp.res->rec) jp.res->rec = new gcre_recipe();
+          rcp = jp.res->rec;
+          rcp->valid = false;
+          const size_t rows = (size_t)P;
+          hipError_t e = rcp->row0.reserve(rows + 64);
+          if (e == hipSuccess) e = rcp->rowz.reserve(rows + 64);
+          if (e == hipSuccess) e = rcp->linfo.reserve(rows + 64);
+          if (e == hipSuccess) e = rcp->lover.reserve(rows + 64);
+          if (e == hipSuccess) e = rcp->slot.reserve(rows * 8 + 64);
+          if (e == hipSuccess) e = rcp->over.reserve(std::max<size_t>(rcp->over.cap, rows * 2 + ((size_t)1 << 26)));
+          if (e != hipSuccess) {
+            (void)hipGetLastError();
+            rcp->release();
+            rcp = nullptr;
+          } else {
+            want_out = plane_bytes(c, jp.res->nrows, out_groups) <= c->planes_out_max || use_rec;
+          }
+        }
+        if (want_out) {
+          res_planes = alloc_planes(c, jp.res, out_groups);
+          res_planes_ok = res_planes;
+        } else {
+          drop_planes(jp.res);   // nothing stale stays behind
+        }
       }
     }
     c->prof.prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
@@ -854,11 +944,13 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         sa.count = n;
         sa.S = g.S;
         sa.Wp = g.Wp;
-        const bool use_ie = want_ie && (sg.score || res_planes);
+        const bool use_ie = want_ie && (sg.score || res_planes || rcp != nullptr);
         const bool use_sparse = sg.score && sparse_ok && !want_ie;
         if (use_sparse || use_ie) {
           collect_ie_stat();
-          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 32, st));
+          // flags of this chunk; the long-list counter (word 4) runs on across the chunks of a join that keeps a recipe
+          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, (rcp && recipe_started) ? 16 : 32, st));
+          recipe_started = recipe_started || rcp != nullptr;
           sa.max_tot = c->d_max_tot;
           HIP_TRY(c, c->d_dcnt.reserve((size_t)n * g.method));
           sa.dcnt = c->d_dcnt.p;
@@ -875,14 +967,24 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sa.zindex = hinted ? u.d_red_index : nullptr;
           sa.excess = hinted ? c->d_excess.p : nullptr;
           sa.range_of = hinted ? u.d_range_of : nullptr;
-          sa.rowz = c->d_rowz.p;
           sa.bad = c->d_max_tot + 1;
           sa.ie_bias = 8;
-          sa.linfo = c->d_linfo.p;
-          sa.lover = c->d_lover.p;
-          sa.slot = c->d_dlist.p;
-          sa.over = c->d_dover.p;
-          sa.over_cap = (uint32_t)std::min<size_t>(c->d_dover.cap - 16, 0xfffffff0u);
+          if (rcp) {   // straight into the recipe of the kept set (absolute row = cb + i)
+            sa.rowz = rcp->rowz.p + cb;
+            sa.linfo = rcp->linfo.p + cb;
+            sa.lover = rcp->lover.p + cb;
+            sa.slot = rcp->slot.p + (size_t)cb * 8;
+            sa.over = rcp->over.p;
+            sa.over_cap = (uint32_t)std::min<size_t>(rcp->over.cap - 16, 0xfffffff0u);
+            HIP_TRY(c, hipMemcpyAsync(rcp->row0.p + cb, c->d_row0.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+          } else {
+            sa.rowz = c->d_rowz.p;
+            sa.linfo = c->d_linfo.p;
+            sa.lover = c->d_lover.p;
+            sa.slot = c->d_dlist.p;
+            sa.over = c->d_dover.p;
+            sa.over_cap = (uint32_t)std::min<size_t>(c->d_dover.cap - 16, 0xfffffff0u);
+          }
           sa.ov_count = c->d_max_tot + 4;
           sa.zoff = (uint32_t)(64 * g.Wp) << 8;
           HIP_TRY(c, launch_stats_ie(sa, g.method, st));
@@ -901,9 +1003,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // max carriers, hint broken, overlap lists, -, long-list entries
           HIP_TRY(c, hipMemcpyAsync(flags, c->d_max_tot, 32, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipStreamSynchronize(st));
-          if ((size_t)flags[4] + 16 > c->d_dover.cap) {
-            // more long lists than the area holds: size it from what the pass asked for, run the chunk again
-            HIP_TRY(c, c->d_dover.reserve((size_t)flags[4] + (size_t)flags[4] / 4 + 64));
+          if ((size_t)flags[4] + 16 > (rcp ? rcp->over.cap : c->d_dover.cap)) {
+            // more long lists than the area holds: size it from what the pass asked for, run the chunk again (a recipe
+            // keeps what the earlier chunks wrote; the failed attempt's reservation is simply left unused)
+            const size_t want = (size_t)flags[4] + (size_t)flags[4] / 4 + ((size_t)1 << 24);
+            if (rcp) HIP_TRY(c, rcp->over.grow_keep(want, rcp->over.cap, st));
+            else HIP_TRY(c, c->d_dover.reserve(want));
             redo = true;
             break;
           }
@@ -916,6 +1021,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             hinted = false;
             if (int rc = prepare_z()) return rc;
             if (!have_pz) want_ie = false;
+            if (cb > sg.b || &sg != &segs.front()) recipe_broken = true;   // earlier chunks added rows of another set
             redo = true;
             break;
           }
@@ -928,15 +1034,19 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             const double dense_cost = 2.0 * g.Wp * g.method * (double)g.K * 2.0 / 65.0;
             if (ie_cost >= dense_cost) { res_planes_ok = false; break; }
           }
+          if (!sg.score && !res_planes) {   // rows of another shard that only needed their recipe entries
+            ran_sparse = true;
+            break;
+          }
           int planes = 5;
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           IeArgs ia{};
           if (int rc = sparse_segments(c, u, cb, n, &ia.segs, &ia.nsegs)) return rc;
           ia.mt = w_mt;
           ia.tot = c->d_tot.p;
-          ia.rowz = c->d_rowz.p;
-          ia.planes0 = have_p0 ? jp.p0->d_planes : nullptr;
-          ia.g0 = have_p0 ? jp.p0->plane_groups : 0;
+          ia.rowz = rcp ? rcp->rowz.p + cb : c->d_rowz.p;
+          ia.planes0 = (have_p0 && !use_rec) ? jp.p0->d_planes : nullptr;
+          ia.g0 = (have_p0 && !use_rec) ? jp.p0->plane_groups : 0;
           ia.planesz = have_pz ? red->d_planes : nullptr;
           ia.gz = have_pz ? red->plane_groups : 0;
           ia.rows0 = (uint32_t)(jp.p0->nrows * g.method);
@@ -944,10 +1054,25 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.rows_out = res_planes ? (uint32_t)(jp.res->nrows * g.method) : 0u;
           ia.loff0 = jp.p0->d_loff;
           ia.lidx0 = jp.p0->d_lidx;
-          ia.linfo = c->d_linfo.p;
-          ia.lover = c->d_lover.p;
-          ia.dlist = c->d_dlist.p;
-          ia.dover = c->d_dover.p;
+          ia.linfo = rcp ? rcp->linfo.p + cb : c->d_linfo.p;
+          ia.lover = rcp ? rcp->lover.p + cb : c->d_lover.p;
+          ia.dlist = rcp ? rcp->slot.p + (size_t)cb * 8 : c->d_dlist.p;
+          ia.dover = rcp ? rcp->over.p : c->d_dover.p;
+          if (use_rec) {
+            const gcre_recipe* r0 = jp.p0->rec;
+            ia.rec_row0 = r0->row0.p;
+            ia.rec_rowz = r0->rowz.p;
+            ia.rec_linfo = r0->linfo.p;
+            ia.rec_lover = r0->lover.p;
+            ia.rec_slot = r0->slot.p;
+            ia.rec_over = r0->over.p;
+            ia.rec_planes_a = rec_a->d_planes;
+            ia.rec_planes_z = rec_z->d_planes;
+            ia.rec_rows_a = (uint32_t)rec_a->nrows;
+            ia.rec_rows_z = (uint32_t)rec_z->nrows;
+            ia.rec_ga = rec_a->plane_groups;
+            ia.rec_gz = rec_z->plane_groups;
+          }
           ia.t32 = c->d_t32;
           ia.d64 = c->d_dmax;
           ia.ladder = c->d_ladder;
@@ -966,7 +1091,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           c->prof.null_row_loads += ((have_p0 ? 0.0 : (double)row_max(c, jp.p0) * g.method * (double)nseg_est) + (double)n_list) * nkt_sp;
           int dev_cus = 256;
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-          const int wpc = std::min(c->sparse_waves_per_cu, ie_max_waves_per_cu(g.method, planes, ia.gz, ia.planes_out != nullptr));
+          const int wpc = std::min(c->sparse_waves_per_cu, ie_max_waves_per_cu(g.method, planes, ia.gz, ia.planes_out != nullptr, ia.rec_slot != nullptr));
           ia.waves_per_xcd = std::max(4, (dev_cus * wpc / 8 / 4) * 4);
           // small joins: a wave's fixed costs (cold TLB and caches, LDS set-up, threshold exchange) are per tile, so give
           // every wave at least ~32 joined paths per tile
@@ -1173,6 +1298,16 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       }
     }
     collect_ie_stat();
+    if (rcp && want_ie && !recipe_broken) {
+      // the recipe names its operands by id and row version: the set paths0 was, and the rows the join really added
+      rcp->a_id = jp.p0->id;
+      rcp->a_ver = jp.p0->version;
+      rcp->z_id = red->id;
+      rcp->z_ver = red->version;
+      rcp->valid = true;
+      jp.res->max_bits = (join_max_tot + 3u) & ~3u;
+      jp.res->max_known = true;
+    }
     keep_planes_done = res_planes && res_planes_ok && g.K > 0;
     keep_max_tot = join_max_tot;
     if (ie_ran && hinted) c->prof.ie_hinted_joins++;
@@ -1291,6 +1426,7 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   if (const char* e = std::getenv("GCRE_NULL_KERNEL"))
     c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : !std::strcmp(e, "ie") ? 3 : 0;
   if (const char* e = std::getenv("GCRE_IE_PRUNE")) c->ie_prune = std::atoi(e) != 0;
+  if (const char* e = std::getenv("GCRE_PLANES_OUT_MAX_MB")) c->planes_out_max = (size_t)std::max(0ll, std::atoll(e)) << 20;
   if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));
 
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -1488,15 +1624,22 @@ int gcre_set_perm_window(gcre_ctx* c, int k0, int k1) {
   return GCRE_OK;
 }
 
-int gcre_plan_perm_window(gcre_ctx* c, int64_t kept_rows) {
-  if (!c || kept_rows < 0) return GCRE_ERR_ARG;
+int gcre_plan_perm_window(gcre_ctx* c, const int64_t* set_rows, int n_sets) {
+  if (!c || n_sets < 0 || (n_sets > 0 && !set_rows)) return GCRE_ERR_ARG;
   const int K = c->g.K;
   const int nkt = (K + kSparseTile - 1) / kSparseTile;
   if (nkt <= 1 || !sparse_enabled(c)) return K;
   (void)hipSetDevice(c->device);
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return K;
-  const double per_tile = (double)std::max<int64_t>(kept_rows, 1) * c->g.method * 4096.0;
+  // sets that store their planes: all of them for the signed method; for method 1 the ones under the recipe limit
+  // (larger kept sets leave a recipe instead, and operands that are not kept are small)
+  double rows = 1;
+  for (int i = 0; i < n_sets; i++) {
+    const double full = (double)std::max<int64_t>(set_rows[i], 0) * c->g.method * 4096.0 * nkt;
+    if (c->g.method != 1 || full <= (double)c->planes_out_max) rows += (double)std::max<int64_t>(set_rows[i], 0);
+  }
+  const double per_tile = rows * c->g.method * 4096.0;
   int64_t tiles = (int64_t)((double)free_b * 0.5 / per_tile);
   if (const char* e = std::getenv("GCRE_WINDOW_TILES")) tiles = std::max(1, std::atoi(e));   // tests
   if (tiles >= nkt) return K;
@@ -1626,8 +1769,12 @@ void gcre_pathset_free(gcre_pathset* ps) {
     if (ps->ctx->stream) (void)hipStreamSynchronize(ps->ctx->stream);
   }
   if (ps->d_rows) (void)hipFree(ps->d_rows);
-  if (ps->d_loff) (void)hipFree(ps->d_loff);
-  if (ps->d_lidx) (void)hipFree(ps->d_lidx);
+  drop_lists(ps);   // lists, and the plane buffer goes to the context's pool
+  if (ps->rec) {
+    ps->rec->release();
+    delete ps->rec;
+  }
+  if (ps->ctx) ps->ctx->live_sets.erase(ps->id);
   delete ps;
 }
 
@@ -1825,20 +1972,23 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
   // Large permutation counts run in windows of whole 2048-permutation tiles: the count planes of the kept sets are per
   // tile, and a window is as many tiles as fit next to the rows.  Scores and top-k lists do not depend on the window (the
   // first window's are returned); the null maxima of the windows are concatenated.
-  int64_t kept_rows = in->data1_rows + in->data2_rows;
+  std::vector<int64_t> set_rows = {in->data1_rows, in->data2_rows};
   for (int lv = 0; lv < 4 && lv <= L; lv++)
-    if (lv != 1) kept_rows += total_paths(in->level[lv]);
+    if (lv != 1) set_rows.push_back(total_paths(in->level[lv]));
   const int Kall = c->g.K;
-  int win = std::max(1, gcre_plan_perm_window(c, kept_rows));
+  int win = std::max(1, gcre_plan_perm_window(c, set_rows.data(), (int)set_rows.size()));
   if (Kall > kSparseTile && sparse_enabled(c)) {
     // A context without a pooled plane buffer of the full size (the R shim makes a fresh context per call, as the
     // reference does) has to hipMalloc the planes: ~40 ms per GB here, 3 KB per kept row and tile.  Against ~25 ms of
     // repeated inspector work per extra window, few tiles per window win: w* = sqrt(25 ms * tiles / (ms per tile)).
-    int64_t biggest = 0;
-    for (int lv = 0; lv < 4 && lv <= L; lv++)
-      if (lv != 1) biggest = std::max(biggest, total_paths(in->level[lv]));
-    const double ms_per_tile = (double)biggest * c->g.method * 3072.0 / 1e9 * 40.0;
+    // (Method 1: a set above the recipe limit stores no planes.)
     const int nkt_all = (Kall + kSparseTile - 1) / kSparseTile;
+    int64_t biggest = 0;
+    for (size_t i = 2; i < set_rows.size(); i++) {
+      const double full = (double)set_rows[i] * c->g.method * 3072.0 * nkt_all;
+      if (c->g.method != 1 || full <= (double)c->planes_out_max) biggest = std::max(biggest, set_rows[i]);
+    }
+    const double ms_per_tile = (double)biggest * c->g.method * 3072.0 / 1e9 * 40.0;
     const size_t full_bytes = (size_t)biggest * c->g.method * 3072 * (size_t)((win + kSparseTile - 1) / kSparseTile);
     bool pooled = false;
     for (const auto& pb : c->plane_pool) pooled = pooled || pb.bytes >= full_bytes;

@@ -211,6 +211,27 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
         const u64 r = (u64)row0 * M + h;
         if (a.planes0) {
           load_planes(B[h], a.planes0, (u32)(((u64)kt * (u64)a.rows0 + r) * (u64)a.g0), a.g0);
+        } else if (M == 1 && a.rec_slot) {
+          // the set has the recipe of the join that made it (see k_null_ie_m1): A[row0'] + Z[z'] -/+ that join's list
+          const u32 ra = a.rec_row0[row0], rz = a.rec_rowz[row0] & 0x7fffffffu, rinfo = a.rec_linfo[row0];
+          u32 ZR[L], S[L];
+          load_planes(B[h], a.rec_planes_a, (u32)(((u64)kt * (u64)a.rec_rows_a + ra) * (u64)a.rec_ga), a.rec_ga);
+          load_planes(ZR, a.rec_planes_z, (u32)(((u64)kt * (u64)a.rec_rows_z + rz) * (u64)a.rec_gz), a.rec_gz);
+#pragma unroll
+          for (int l = 0; l < L; l++) S[l] = 0u;
+          const u32 rlen = rinfo & ~7u;
+          stream(S, (const u32 GCRE_CONSTANT*)(a.rec_slot + (u64)row0 * 8u), 0, 8);
+          if (rlen > 8u) stream(S, (const u32 GCRE_CONSTANT*)(a.rec_over + a.rec_lover[row0]), 0, (u64)(rlen - 8u));
+          u32 cy = 0u, bw = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            const u32 zl = (rinfo & 1u) ? ZR[l] : S[l];        // overlap list: + Z - S; delta list: + S
+            const u32 sl_ = (rinfo & 1u) ? S[l] : 0u;
+            const u32 s1_ = B[h][l] ^ zl ^ cy;
+            cy = maj3(B[h][l], zl, cy);
+            B[h][l] = s1_ ^ sl_ ^ bw;
+            bw = maj3(~s1_, sl_, bw);
+          }
         } else {
 #pragma unroll
           for (int l = 0; l < L; l++) B[h][l] = 0u;
@@ -323,7 +344,7 @@ __device__ __forceinline__ void sum8(const u32 (&r)[8], u32 (&s)[4]) {
   s[3] = d0 & d1;
 }
 
-template <int L, int GZ, bool OUT>
+template <int L, int GZ, bool OUT, bool REC>
 __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
   static_assert(L % 4 == 0 && L >= 8 && L <= 16 && GZ >= 2 && GZ <= L / 4, "planes come in groups of 4");
   // the waves' running maxima: [q][lane] per wave; touched only by the few lookups that survive the interval test
@@ -435,15 +456,76 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       // through the scalar cache, one s_load_dwordx8 per path, fetched one path ahead of the loads that use them
       typedef u32 __attribute__((ext_vector_type(8))) u32x8;
       const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 8u);
-      // ---- base counters: the planes of paths0[row0] ----
+      // ---- base counters: the planes of paths0[row0] -- stored, or (REC) rebuilt from the recipe of the join that
+      // produced the row: planes of ITS paths0 row + planes of the row it added -/+ its 8-entry list ----
       u32 B[L];
-      {
-        const u32x4* src = (const u32x4*)(a.planes0 + (((u64)kt * (u64)a.rows0 + (u64)row0) * (u64)a.g0) * 256u) + lane;
+      auto load_groups = [&](u32 (&P)[L], const u32* planes, u64 unit, int groups) {
+        const u32x4* src = (const u32x4*)(planes + unit * 256u) + lane;
 #pragma unroll
         for (int j = 0; j < L / 4; j++) {
           u32x4 v = {0u, 0u, 0u, 0u};
-          if (j < a.g0) v = src[j * 64];
-          B[4 * j + 0] = v.x; B[4 * j + 1] = v.y; B[4 * j + 2] = v.z; B[4 * j + 3] = v.w;
+          if (j < groups) v = src[j * 64];
+          P[4 * j + 0] = v.x; P[4 * j + 1] = v.y; P[4 * j + 2] = v.z; P[4 * j + 3] = v.w;
+        }
+      };
+      if constexpr (!REC) {
+        load_groups(B, a.planes0, ((u64)kt * (u64)a.rows0 + (u64)row0) * (u64)a.g0, a.g0);
+      } else {
+        const u32 GCRE_CONSTANT* r_row0 = (const u32 GCRE_CONSTANT*)a.rec_row0;
+        const u32 GCRE_CONSTANT* r_rowz = (const u32 GCRE_CONSTANT*)a.rec_rowz;
+        const u32 GCRE_CONSTANT* r_info = (const u32 GCRE_CONSTANT*)a.rec_linfo;
+        const u32 GCRE_CONSTANT* r_lov = (const u32 GCRE_CONSTANT*)a.rec_lover;
+        const u32 ra = r_row0[row0], rz = r_rowz[row0] & 0x7fffffffu, rinfo = r_info[row0];
+        const u32x8 ro = *(const u32x8 GCRE_CONSTANT*)((const u32 GCRE_CONSTANT*)a.rec_slot + (u64)row0 * 8u);
+        u32 yr[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) yr[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, ro[j], 0);
+        u32 ZR[L];
+        load_groups(B, a.rec_planes_a, ((u64)kt * (u64)a.rec_rows_a + (u64)ra) * (u64)a.rec_ga, a.rec_ga);
+        load_groups(ZR, a.rec_planes_z, ((u64)kt * (u64)a.rec_rows_z + (u64)rz) * (u64)a.rec_gz, a.rec_gz);
+        u32 S[L];
+        {
+          u32 S4[4];
+          sum8(yr, S4);
+#pragma unroll
+          for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
+        }
+        const u32 rlen = rinfo & ~7u;
+        if (rlen > 8u) {   // the producing join's list was long: the rest of it, 8 entries at a time
+          const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.rec_over + r_lov[row0]);
+          for (u32 p = 0u; p + 8u < rlen; p += 8u) {
+            const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
+            u32 yy[8], s4[4];
+#pragma unroll
+            for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o8[j], 0);
+            sum8(yy, s4);
+            u32 cy = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              const u32 sv = S[l];
+              const u32 add = (l < 4) ? s4[l < 4 ? l : 0] : 0u;
+              S[l] = xor3(sv, add, cy);
+              cy = majority(sv, add, cy);
+            }
+          }
+        }
+        if (rinfo & 1u) {   // B = A + Z - S
+          u32 cy = 0u, bw = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            const u32 s1_ = xor3(B[l], ZR[l], cy);
+            cy = majority(B[l], ZR[l], cy);
+            B[l] = xor3(s1_, S[l], bw);
+            bw = borrow3(s1_, S[l], bw);
+          }
+        } else {            // B = A + S
+          u32 cy = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            const u32 bl = B[l];
+            B[l] = xor3(bl, S[l], cy);
+            cy = majority(bl, S[l], cy);
+          }
         }
       }
 
@@ -636,15 +718,18 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
   else if (planes <= 12) { EXPR(2, 12); }   \
   else { EXPR(2, 16); }
 
+#define GCRE_IE_M1_OR(EXPR, LL, GG)                                                  \
+  if (out) { if (rec) { EXPR(LL, GG, true, true); } else { EXPR(LL, GG, true, false); } }   \
+  else { if (rec) { EXPR(LL, GG, false, true); } else { EXPR(LL, GG, false, false); } }
+
 #define GCRE_IE_M1(EXPR)                                                     \
-  if (planes <= 8) { if (out) { EXPR(8, 2, true); } else { EXPR(8, 2, false); } }            \
+  if (planes <= 8) { GCRE_IE_M1_OR(EXPR, 8, 2) }                             \
   else if (planes <= 12) {                                                   \
-    if (gz <= 2) { if (out) { EXPR(12, 2, true); } else { EXPR(12, 2, false); } }            \
-    else { if (out) { EXPR(12, 3, true); } else { EXPR(12, 3, false); } }                    \
+    if (gz <= 2) { GCRE_IE_M1_OR(EXPR, 12, 2) } else { GCRE_IE_M1_OR(EXPR, 12, 3) }        \
   } else {                                                                   \
-    if (gz <= 2) { if (out) { EXPR(16, 2, true); } else { EXPR(16, 2, false); } }            \
-    else if (gz == 3) { if (out) { EXPR(16, 3, true); } else { EXPR(16, 3, false); } }       \
-    else { if (out) { EXPR(16, 4, true); } else { EXPR(16, 4, false); } }                    \
+    if (gz <= 2) { GCRE_IE_M1_OR(EXPR, 16, 2) }                              \
+    else if (gz == 3) { GCRE_IE_M1_OR(EXPR, 16, 3) }                         \
+    else { GCRE_IE_M1_OR(EXPR, 16, 4) }                                      \
   }
 
 #define GCRE_IE_GEN(EXPR)                                          \
@@ -664,7 +749,8 @@ hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general,
   if (method == 1 && !general) {
     const int gz = a.gz;
     const bool out = a.planes_out != nullptr;
-#define GCRE_LAUNCH(LL, GG, OO) hipLaunchKernelGGL((k_null_ie_m1<LL, GG, OO>), grid, block, 0, stream, a)
+    const bool rec = a.rec_slot != nullptr;
+#define GCRE_LAUNCH(LL, GG, OO, RR) hipLaunchKernelGGL((k_null_ie_m1<LL, GG, OO, RR>), grid, block, 0, stream, a)
     GCRE_IE_M1(GCRE_LAUNCH)
 #undef GCRE_LAUNCH
   } else {
@@ -675,11 +761,11 @@ hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general,
   return hipGetLastError();
 }
 
-int ie_max_waves_per_cu(int method, int planes, int gz, bool out) {
+int ie_max_waves_per_cu(int method, int planes, int gz, bool out, bool rec) {
   int blocks = 0;
   hipError_t e = hipSuccess;
   if (method == 1) {
-#define GCRE_OCC(LL, GG, OO) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m1<LL, GG, OO>, 64 * kIeWaves, 0)
+#define GCRE_OCC(LL, GG, OO, RR) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m1<LL, GG, OO, RR>, 64 * kIeWaves, 0)
     GCRE_IE_M1(GCRE_OCC)
 #undef GCRE_OCC
   } else {

@@ -99,6 +99,18 @@ struct IeArgs {
   const uint32_t* planes0;   // count planes of paths0 [tile][row*M+h][g0][64][4], or nullptr: stream loff0/lidx0
   const uint32_t* planesz;   // count planes of the reduced operand [tile][row*M+h][gz][64][4] (mode-1 paths)
   uint32_t rows0, rowsz, rows_out;   // row-halves (rows * M) of the three plane arrays
+  // method 1, paths0 without stored planes but with the recipe of the join that produced it (rec_slot != nullptr): row r of
+  // paths0 = row rec_row0[r] of set A | row rec_rowz[r] of set Z, list info / slot / overflow as that join's inspector left them
+  const uint32_t* rec_row0;
+  const uint32_t* rec_rowz;
+  const uint32_t* rec_linfo;
+  const uint32_t* rec_lover;
+  const uint32_t* rec_slot;
+  const uint32_t* rec_over;
+  const uint32_t* rec_planes_a;
+  const uint32_t* rec_planes_z;
+  uint32_t rec_rows_a, rec_rows_z;
+  int rec_ga, rec_gz;
   const uint64_t* loff0;
   const uint32_t* lidx0;
   const uint32_t* linfo;     // per list (path*M + half): padded length (multiple of 8, >= 8) | mode (bit 0: 1 = overlap list)
@@ -124,7 +136,7 @@ struct IeArgs {
   uint32_t mt_rows, zoff;
 };
 hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general, hipStream_t stream);
-int ie_max_waves_per_cu(int method, int planes, int gz, bool out);
+int ie_max_waves_per_cu(int method, int planes, int gz, bool out, bool rec);
 hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, const uint64_t* loff, const uint32_t* lidx,
                                int64_t nrowhalves, int groups, uint32_t* planes, hipStream_t stream);
 hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipStream_t stream);

@@ -239,10 +239,11 @@ uint64_t gcre_mix64(uint64_t z);
  * run a large permutation count in batches whose count planes (one per kept row and 2048-permutation tile) fit in device
  * memory -- gcre_process_paths does so on its own.  Setting masks resets the window to [0, iterations). */
 int gcre_set_perm_window(gcre_ctx* ctx, int k0, int k1);
-/* Window length (permutations; a multiple of 2048, or iterations when everything fits) for a pipeline whose kept path sets
- * hold `kept_rows` rows in total: their count planes take up to 4 KB per row, method half and tile, and should leave half
- * of the free device memory alone. */
-int gcre_plan_perm_window(gcre_ctx* ctx, int64_t kept_rows);
+/* Window length (permutations; a multiple of 2048, or iterations when everything fits) for a pipeline whose path sets --
+ * the inputs and the kept sets -- hold set_rows[i] rows: the count planes of a set take up to 4 KB per row, method half
+ * and tile (method 1: sets above the recipe limit, GCRE_PLANES_OUT_MAX_MB, store none) and should leave half of the free
+ * device memory alone. */
+int gcre_plan_perm_window(gcre_ctx* ctx, const int64_t* set_rows, int n_sets);
 /* read permutation mask r back as width_ul words (bit c = patient c is a case under permutation r) */
 int gcre_get_perm_mask(gcre_ctx* ctx, int r, uint64_t* out);
 

@@ -231,3 +231,30 @@ def test_wide_counters_and_dense_rows(method, density, n, monkeypatch):
     want = oracle.process_paths(p, order="canonical")
     check_levels(got, want, range(1, 5))
     assert got["profile"]["ie_launches"] >= 5 and got["profile"]["ie_hinted_joins"] == 5
+
+
+@pytest.mark.parametrize("limit_mb", ["0", "100000"])
+@pytest.mark.parametrize("world", [1, 2])
+def test_recipes_replace_stored_planes(limit_mb, world, monkeypatch):
+    """A kept method-1 set leaves the recipe of the join that made it; whether its planes are also stored (small sets)
+    or rebuilt inside the next level's kernel from the recipe (GCRE_PLANES_OUT_MAX_MB=0: every set whose paths0 had
+    stored planes) must not show in any result -- one device or two shards, with permutation windows on top."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_PLANES_OUT_MAX_MB", limit_mb)
+    monkeypatch.setenv("GCRE_WINDOW_TILES", "1")
+    p = sparse_problem("method1", 14, K=2300, L=5)
+    want = oracle.process_paths(p, order="canonical")
+    if world == 1:
+        check_levels(api.process_paths(p), want, range(1, 6))
+    parts = []
+    for rank in range(world):
+        plan = api.ResidentPlan(p)
+        parts.append(plan.run(rank=rank, world=world))
+        plan.close()
+    for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4), ("5", 5)):
+        null = np.maximum.reduce([r[name].null for r in parts])
+        rows = [np.stack([r[name].scores, r[name].src, r[name].trg, r[name].cases, r[name].ctrls], axis=1) for r in parts]
+        best = dist.merge_topk(np.vstack(rows), p.top_k)
+        w = want[f"lst{lvl}"]
+        np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
