@@ -837,34 +837,76 @@ hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, co
 // an empty interval is lo = 1, hi = 0 (every count is "outside").  Valid for ANY table: cells outside the interval
 // are simply looked up.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_build_ladder(const u32* t32, int TD, u32* ladder) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per diagonal.  A cell c with value d[c] blocks the levels j with j/kLadderPerUnit < d[c], i.e. j < J(c) =
+// ceil(kLadderPerUnit * d[c]); the interval of level j ends next to the nearest blocking cell on either side of the
+// diagonal's (first) minimum c0:  lo_j = 1 + max{c < c0 : J(c) > j},  hi_j = min{c > c0 : J(c) > j} - 1.
+__global__ __launch_bounds__(64) void k_build_ladder(const u32* t32, int TD, u32* ladder) {
+  __shared__ int left[kLadderLevels + 2], right[kLadderLevels + 2];
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x;
   if (t >= TD) return;
   const u32* d = t32 + sp_diag_offset((u32)t);
-  int c0 = 0;
-  u32 best = d[0];
-  for (int c = 1; c <= t; c++)
-    if (d[c] < best) { best = d[c]; c0 = c; }
-  int lo = c0 + 1, hi = c0;   // empty
-  for (int j = 0; j < kLadderLevels; j++) {
-    const u32 th = __float_as_uint((float)j / (float)kLadderPerUnit);
-    if (lo > hi && best <= th) lo = hi = c0;
-    if (lo <= hi) {
-      while (lo > 0 && d[lo - 1] <= th) lo--;
-      while (hi < t && d[hi + 1] <= th) hi++;
-      ladder[(size_t)j * TD + t] = ((u32)hi << 16) | (u32)lo;
-    } else {
-      ladder[(size_t)j * TD + t] = 1u;   // lo = 1, hi = 0
+  for (int k = lane; k < kLadderLevels + 2; k += 64) {
+    left[k] = -1;
+    right[k] = t + 1;
+  }
+  // first minimum of the diagonal (values are bit patterns of non-negative floats: they order like the floats)
+  u64 mine = ~(u64)0;
+  for (int c = lane; c <= t; c += 64) {
+    const u64 key = ((u64)d[c] << 32) | (u32)c;
+    mine = key < mine ? key : mine;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 other = ((u64)(u32)__shfl_xor((int)(mine >> 32), o, 64) << 32) | (u32)__shfl_xor((int)(u32)mine, o, 64);
+    mine = other < mine ? other : mine;
+  }
+  const u32 best = (u32)(mine >> 32);
+  const int c0 = (int)(u32)mine;
+  __syncthreads();
+  auto blocked_below = [](u32 bits) -> int {   // J: number of levels whose threshold is below the value
+    const float v = __uint_as_float(bits);
+    if (!(v > 0.0f)) return 0;
+    const float x = v * (float)kLadderPerUnit;
+    if (x >= (float)kLadderLevels) return kLadderLevels;
+    const int j = (int)x;                        // thresholds j/8 are exact in f32, and so is x = 8 v
+    return ((float)j < x) ? j + 1 : j;
+  };
+  for (int c = lane; c <= t; c += 64) {
+    if (c == c0) continue;
+    const int J = blocked_below(d[c]);
+    if (J == 0) continue;
+    if (c < c0) atomicMax(&left[J], c);
+    else atomicMin(&right[J], c);
+  }
+  __syncthreads();
+  if (lane == 0) {   // suffix max / min over J: a cell with J blocks every level below J
+    int l = -1, r = t + 1;
+    for (int k = kLadderLevels; k >= 0; k--) {
+      l = left[k] > l ? left[k] : l;
+      r = right[k] < r ? right[k] : r;
+      left[k] = l;
+      right[k] = r;
     }
   }
-  // two constant rows behind the levels: "every count is inside" (nothing is looked up: planes-only launches) and
-  // "every count is outside" (everything is looked up: GCRE_IE_PRUNE=0)
-  ladder[(size_t)kLadderLevels * TD + t] = 0xffff0000u;
-  ladder[(size_t)(kLadderLevels + 1) * TD + t] = 1u;
+  __syncthreads();
+  const int Jbest = blocked_below(best);
+  for (int j = lane; j < kLadderLevels; j += 64) {
+    // level j is blocked by cells with J > j: left[j + 1] / right[j + 1] after the suffix pass
+    u32 e = 1u;   // lo = 1, hi = 0: empty
+    if (Jbest <= j) e = ((u32)(right[j + 1] - 1) << 16) | (u32)(left[j + 1] + 1);
+    ladder[(size_t)j * TD + t] = e;
+  }
+  if (lane == 0) {
+    // two constant rows behind the levels: "every count is inside" (nothing is looked up: planes-only launches) and
+    // "every count is outside" (everything is looked up: GCRE_IE_PRUNE=0)
+    ladder[(size_t)kLadderLevels * TD + t] = 0xffff0000u;
+    ladder[(size_t)(kLadderLevels + 1) * TD + t] = 1u;
+  }
 }
 
 hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipStream_t stream) {
-  hipLaunchKernelGGL(k_build_ladder, dim3((unsigned)((TD + 63) / 64)), dim3(64), 0, stream, (const u32*)t32, TD, ladder);
+  hipLaunchKernelGGL(k_build_ladder, dim3((unsigned)TD), dim3(64), 0, stream, (const u32*)t32, TD, ladder);
   return hipGetLastError();
 }
 
