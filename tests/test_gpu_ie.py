@@ -214,13 +214,21 @@ def test_perm_window_arguments():
     ex.close()
 
 
+@pytest.mark.parametrize("recipes", [False, True])
 @pytest.mark.parametrize("method,density,n", [("method1", 0.45, 1600), ("method2", 0.45, 1600), ("method1", 0.3, 9000),
                                                ("method2", 0.3, 9000), ("method1", 0.02, 9000)])
-def test_wide_counters_and_dense_rows(method, density, n, monkeypatch):
+def test_wide_counters_and_dense_rows(method, density, n, recipes, monkeypatch):
     """Every counter width of the IE kernels: dense rows over 1,600 patients (12 planes, gene planes of 3 groups, long
     overlap and delta lists through the overflow area) and over 9,000 patients (16 planes, up to 4 groups), plus rare
-    variants over 9,000 patients (141 words per row: the inspector's 10-pass row loop)."""
+    variants over 9,000 patients (141 words per row: the inspector's 10-pass row loop).  With ``recipes`` no kept
+    method-1 set whose paths0 had planes stores its own: the next level rebuilds every base row from the recipe,
+    long lists included; small chunks make the recipe span several inspector passes."""
     monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    if recipes:
+        if method == "method2":
+            pytest.skip("the signed method stores planes")
+        monkeypatch.setenv("GCRE_PLANES_OUT_MAX_MB", "0")
+        monkeypatch.setenv("GCRE_CHUNK_PATHS", "192")
     nc = n // 2 - 37
     p = make_problem(24, 55, nc, n - nc, 130, 4, method=method, top_k=9, seed=21, threshold=0.9,
                      table=small_table(nc, n - nc, 4))
