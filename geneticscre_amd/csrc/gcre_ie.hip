@@ -346,7 +346,9 @@ __device__ __forceinline__ void sum8(const u32 (&r)[8], u32 (&s)[4]) {
 
 template <int L, int GZ, bool OUT, bool REC>
 __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
-  static_assert(L % 4 == 0 && L >= 8 && L <= 16 && GZ >= 2 && GZ <= L / 4, "planes come in groups of 4");
+  // L counter planes (any even number: the arithmetic runs over exactly L); plane arrays come in groups of 4
+  constexpr int LP = (L + 3) / 4 * 4;
+  static_assert(L >= 8 && L <= 16 && GZ >= 2 && 4 * GZ <= LP, "planes come in groups of 4");
   // the waves' running maxima: [q][lane] per wave; touched only by the few lookups that survive the interval test
   __shared__ u32 nmax_lds[kIeWaves][32 * 64];
   const int lane = threadIdx.x & 63;
@@ -458,11 +460,11 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 8u);
       // ---- base counters: the planes of paths0[row0] -- stored, or (REC) rebuilt from the recipe of the join that
       // produced the row: planes of ITS paths0 row + planes of the row it added -/+ its 8-entry list ----
-      u32 B[L];
-      auto load_groups = [&](u32 (&P)[L], const u32* planes, u64 unit, int groups) {
+      u32 B[LP];
+      auto load_groups = [&](u32 (&P)[LP], const u32* planes, u64 unit, int groups) {
         const u32x4* src = (const u32x4*)(planes + unit * 256u) + lane;
 #pragma unroll
-        for (int j = 0; j < L / 4; j++) {
+        for (int j = 0; j < LP / 4; j++) {
           u32x4 v = {0u, 0u, 0u, 0u};
           if (j < groups) v = src[j * 64];
           P[4 * j + 0] = v.x; P[4 * j + 1] = v.y; P[4 * j + 2] = v.z; P[4 * j + 3] = v.w;
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
         u32 yr[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) yr[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, ro[j], 0);
-        u32 ZR[L];
+        u32 ZR[LP];
         load_groups(B, a.rec_planes_a, ((u64)kt * (u64)a.rec_rows_a + (u64)ra) * (u64)a.rec_ga, a.rec_ga);
         load_groups(ZR, a.rec_planes_z, ((u64)kt * (u64)a.rec_rows_z + (u64)rz) * (u64)a.rec_gz, a.rec_gz);
         u32 S[L];
@@ -641,7 +643,8 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
           for (int j = 0; j < 4; j++) {
             if (j < a.go) {
               u32x4 v = {0u, 0u, 0u, 0u};
-              if (4 * j < L) v = u32x4{C[(4 * j) % L], C[(4 * j + 1) % L], C[(4 * j + 2) % L], C[(4 * j + 3) % L]};
+              if (4 * j < L) v = u32x4{C[(4 * j) % L], (4 * j + 1 < L) ? C[(4 * j + 1) % L] : 0u, (4 * j + 2 < L) ? C[(4 * j + 2) % L] : 0u,
+                                       (4 * j + 3 < L) ? C[(4 * j + 3) % L] : 0u};
               dst[j * 64] = v;
             }
           }
@@ -724,7 +727,9 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
 
 #define GCRE_IE_M1(EXPR)                                                     \
   if (planes <= 8) { GCRE_IE_M1_OR(EXPR, 8, 2) }                             \
-  else if (planes <= 12) {                                                   \
+  else if (planes <= 10) {                                                   \
+    if (gz <= 2) { GCRE_IE_M1_OR(EXPR, 10, 2) } else { GCRE_IE_M1_OR(EXPR, 10, 3) }        \
+  } else if (planes <= 12) {                                                 \
     if (gz <= 2) { GCRE_IE_M1_OR(EXPR, 12, 2) } else { GCRE_IE_M1_OR(EXPR, 12, 3) }        \
   } else {                                                                   \
     if (gz <= 2) { GCRE_IE_M1_OR(EXPR, 16, 2) }                              \
