@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--config", default="roofline", choices=sorted(CONFIGS))
     ap.add_argument("--edges", type=int, default=0, help="override the synthetic network's edge count")
     ap.add_argument("--perms", type=int, default=0)
+    ap.add_argument("--method", default="", choices=["", "method1", "method2"], help="override the config's scoring method")
     ap.add_argument("--top-k", type=int, default=100)
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,6 +214,8 @@ def main():
             dist.init_process_group("gloo")
 
     cfg = dict(CONFIGS[args.config])
+    if args.method:
+        cfg["method"] = args.method
     if args.edges:
         cfg["edges"] = args.edges
     if args.perms:
@@ -288,7 +291,7 @@ def main():
     pmc = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc.json" if ie else "r01_b_pmc_traffic.json")))
-        same = pmc.get("workload") == args.config and not args.edges and not args.perms and world == 1
+        same = pmc.get("workload") == args.config and not args.edges and not args.perms and not args.method and world == 1
         if same and (ie or row_loads > 0):
             roofline["traffic"] = pmc["traffic_bytes_per_null_launch"]
             roofline["traffic_source"] = ("profiles/%s (rocprofv3 FETCH_SIZE + WRITE_SIZE of the null kernels, raw KB x 1024; "

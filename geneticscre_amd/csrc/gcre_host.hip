@@ -1119,7 +1119,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hipEventRecord(n0, st));
           ia.seg_begin = 0;
           ia.seg_end = ia.nsegs;
-          if (g.method == 1 && ia.lad_mode == 0) {
+          if (c->d_ladder && ia.lad_mode == 0) {
             // warm-up: the first segments are scored without pruning (every count looked up, general kernel); what
             // they find seeds the thresholds the pruned kernel starts from.  Joins of a few thousand paths run here whole.
             const int64_t n_warm = std::min<int64_t>(ia.nsegs, std::max<int64_t>(2048, ia.nsegs / 1024));
@@ -1132,7 +1132,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             HIP_TRY(c, launch_null_ie(wa, g.method, planes, true, st));
             ia.seg_begin = n_warm;
           }
-          if (ia.seg_begin < ia.seg_end) HIP_TRY(c, launch_null_ie(ia, g.method, planes, false, st));
+          if (ia.seg_begin < ia.seg_end) HIP_TRY(c, launch_null_ie(ia, g.method, planes, c->d_ladder == nullptr, st));
           HIP_TRY(c, hipEventRecord(n1, st));
           if (timing) {
             uint64_t tmv[8] = {0};
@@ -1512,9 +1512,11 @@ int gcre_set_value_table(gcre_ctx* c, const double* table, int nrow, int ncol, i
   if (raw) e = hipMemcpyAsync(d_raw, table, raw * 8, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess)
     e = launch_table_to_diag(d_raw, nrow, ncol, col_major, n, (int)TD, c->d_dvt, c->d_t32, c->d_dmax, c->stream);
-  if (e == hipSuccess && g.method == 1 && TD <= 65536) {   // counts fit the 16-bit bounds of a ladder entry
+  if (e == hipSuccess && TD <= 65536) {   // counts fit the 16-bit bounds of a ladder entry
     if (!c->d_ladder) e = hipMalloc((void**)&c->d_ladder, (size_t)(kLadderLevels + 2) * TD * 4);
-    if (e == hipSuccess) e = launch_build_ladder(c->d_t32, (int)TD, c->d_ladder, c->stream);
+    if (e == hipSuccess)
+      e = g.method == 1 ? launch_build_ladder(c->d_t32, (int)TD, c->d_ladder, c->stream)
+                        : launch_build_ladder2(c->d_dmax, (int)TD, c->d_ladder, c->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d_raw);

@@ -714,6 +714,251 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
   if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
 }
 
+// ------------------------------------------------------------------------------------------------
+// method 2 (signed), pruned.  A joined path has a (+) and a (-) half with their own counts a, b and carrier totals
+// tp, tn; its null score is (float)(vtmax[tp][a] + vtmax[tn][b]) (methods.h:220-230).  For a threshold theta not
+// above any running maximum of the tile, a permutation with vtmax[tp][a] <= theta/2 AND vtmax[tn][b] <= theta/2
+// cannot raise its maximum (the f64 sum is <= theta, rounding to f32 is monotone), so both halves are tested against
+// the half-threshold intervals of their diagonals (k_build_ladder2) and only permutations that fail either test are
+// looked up -- exactly: both cells gathered in f64, added, rounded, clamped at 0.
+// ------------------------------------------------------------------------------------------------
+template <int L, bool OUT>
+__global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
+  constexpr int LP = (L + 3) / 4 * 4;
+  static_assert(L >= 8 && L <= 16, "8 to 16 counter planes");
+  typedef u32 __attribute__((ext_vector_type(8))) u32x8;
+  __shared__ u32 nmax_lds[kIeWaves][32 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7;
+  const i64 wi = (i64)(blockIdx.x >> 3) * kIeWaves + wave;
+  const i64 wx = a.waves_per_xcd;
+  const i64 slices = 8 * wx;
+  const u32 lane4 = (u32)lane * 4u;
+  u32* nm = nmax_lds[wave] + lane;
+#pragma unroll
+  for (int q = 0; q < 32; q++) nm[q * 64] = 0u;
+  const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
+
+  int cur_kt = -1;
+  u32 valid = 0u;
+  u32 lad_base = (a.lad_mode == 0) ? 0u : (u32)(kLadderLevels - 1 + a.lad_mode) * (u32)a.ladder_stride;
+  bool dirty = false;
+  u32 n_slow = 0u;
+  __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)a.mt, 0, 0x7fffffff, 0x00020000);
+
+  auto exchange = [&]() {
+    u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
+    __amdgpu_buffer_rsrc_t nb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.null_bits + (size_t)cur_kt * 2048), 0, 8192, 0x00020000);
+    u32x4 g4[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) g4[j] = __builtin_amdgcn_raw_buffer_load_b128(nb, (u32)lane * 128u + (u32)j * 16u, 0, 16 /* sc1 */);
+    u32 lo = 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      const u32 g = g4[q >> 2][q & 3];
+      const u32 own = nm[q * 64];
+      if (dirty && own > g) atomicMax(out + q, own);
+      const u32 v = own > g ? own : g;
+      if ((valid >> q) & 1u) lo = v < lo ? v : lo;
+    }
+    dirty = false;
+    u32 theta = __builtin_amdgcn_readfirstlane(wave_min_u32(lo));
+    if (theta == 0xffffffffu) theta = 0u;
+    int j = (int)(__uint_as_float(theta) * (float)kLadderPerUnit);   // ladder row j holds the intervals for theta_j / 2
+    j = j < 0 ? 0 : (j > kLadderLevels - 1 ? kLadderLevels - 1 : j);
+    lad_base = (u32)j * (u32)a.ladder_stride;
+  };
+  auto flush_tile = [&]() {
+    if (cur_kt >= 0) {
+      u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
+#pragma unroll 8
+      for (int q = 0; q < 32; q++) {
+        const u32 own = nm[q * 64];
+        if (own != 0u) {
+          atomicMax(out + q, own);
+          nm[q * 64] = 0u;
+        }
+      }
+    }
+    dirty = false;
+  };
+  auto load_groups = [&](u32 (&P)[LP], const u32* planes, u64 unit, int groups) {
+    const u32x4* src = (const u32x4*)(planes + unit * 256u) + lane;
+#pragma unroll
+    for (int j = 0; j < LP / 4; j++) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (j < groups) v = src[j * 64];
+      P[4 * j + 0] = v.x; P[4 * j + 1] = v.y; P[4 * j + 2] = v.z; P[4 * j + 3] = v.w;
+    }
+  };
+  // live permutations whose count lies outside [lo, hi] (bounds as scalar masks, two borrow chains)
+  auto outside = [&](const u32 (&C)[L], u32 lh) -> u32 {
+    const u32 lo = lh & 0xffffu, hi = lh >> 16;
+    u32 blo = 0u, bhi = 0u;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const u32 kl = (u32)__builtin_amdgcn_sbfe((int)lo, l, 1);
+      const u32 kh = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
+      blo = borrow3(C[l], kl, blo);
+      bhi = borrow3(kh, C[l], bhi);
+    }
+    return blo | bhi;
+  };
+
+  for (int step = 0; step < a.nkt; step++) {
+    const i64 item = (i64)xcd * a.nkt * wx + wi + (i64)step * wx;
+    const int kt = (int)(item / slices);
+    const i64 sl = item % slices;
+    if (a.seg_begin + sl >= a.seg_end) continue;
+    if (kt != cur_kt) {
+      flush_tile();
+      cur_kt = kt;
+      mt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mt + (size_t)kt * a.mt_rows * 64), 0, 0x7fffffff, 0x00020000);
+      const int live = a.K - kt * 2048 - lane * 32;
+      valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
+      if (a.lad_mode == 0) lad_base = 0u;
+    }
+    int since = 0, period = 1;
+    for (i64 sidx = a.seg_begin + sl; sidx < a.seg_end; sidx += slices) {
+      const u32 row0 = segs[sidx].row0;
+      const u32 first = segs[sidx].first;
+      const u32 npaths = segs[sidx].n;
+      if (a.lad_mode == 0 && ++since >= period) {
+        exchange();
+        since = 0;
+        period = period < kIeRefresh ? period * 2 : kIeRefresh;
+      }
+      // ---- per-path metadata of the segment: lane t <-> joined path first + t, both halves ----
+      const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
+      const u32 rzv = a.rowz[qv];
+      u32 infov[2], lovv[2], zunit[2], totv[2], lhv[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        infov[h] = a.linfo[(u64)qv * 2 + h];
+        lovv[h] = a.lover[(u64)qv * 2 + h];
+        const u32 hz = (rzv >> 31) ? (u32)(1 - h) : (u32)h;
+        zunit[h] = ((u32)kt * (u32)a.rowsz + (rzv & 0x7fffffffu) * 2u + hz) * (u32)a.gz;
+        totv[h] = a.tot[(u64)qv * 2 + h];
+        lhv[h] = a.ladder[lad_base + totv[h]];
+      }
+      const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 16u);
+      u32 B[2][LP];
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        load_groups(B[h], a.planes0, ((u64)kt * (u64)a.rows0 + (u64)row0 * 2 + h) * (u64)a.g0, a.g0);
+
+      for (u32 t = 0; t < npaths; t++) {
+        u32 C[2][L];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const u32 r0 = rdlane(infov[h], t);
+          const u32 len = r0 & ~7u;
+          const bool overlap = (r0 & 1u) != 0u;
+          const u32x8 offs = slots[t * 2 + h];
+          u32 y[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) y[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+          u32 Z[LP];
+          if (overlap) {
+            load_groups(Z, a.planesz, (u64)rdlane(zunit[h], t), a.gz);
+          } else {
+#pragma unroll
+            for (int l = 0; l < LP; l++) Z[l] = 0u;
+          }
+          u32 S[L];
+          {
+            u32 S4[4];
+            sum8(y, S4);
+#pragma unroll
+            for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
+          }
+          if (len > 8u) {   // long list (rare): further blocks of 8 entries
+            const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + rdlane(lovv[h], t));
+            for (u32 p = 0u; p + 8u < len; p += 8u) {
+              const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
+              u32 yy[8], s4[4];
+#pragma unroll
+              for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o8[j], 0);
+              sum8(yy, s4);
+              u32 cy = 0u;
+#pragma unroll
+              for (int l = 0; l < L; l++) {
+                const u32 sv = S[l];
+                const u32 add = (l < 4) ? s4[l < 4 ? l : 0] : 0u;
+                S[l] = xor3(sv, add, cy);
+                cy = majority(sv, add, cy);
+              }
+            }
+          }
+          if (overlap) {   // C = B + Nz - S
+            u32 cy = 0u, bw = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              const u32 s1_ = xor3(B[h][l], Z[l], cy);
+              cy = majority(B[h][l], Z[l], cy);
+              C[h][l] = xor3(s1_, S[l], bw);
+              bw = borrow3(s1_, S[l], bw);
+            }
+          } else {         // C = B + S
+            u32 cy = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              C[h][l] = xor3(B[h][l], S[l], cy);
+              cy = majority(B[h][l], S[l], cy);
+            }
+          }
+          if constexpr (OUT) {
+            const u64 rh = ((u64)a.out_first + first + t) * 2 + h;
+            u32x4* dst = (u32x4*)(a.planes_out + (((u64)kt * (u64)a.rows_out + rh) * (u64)a.go) * 256u) + lane;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (j < a.go) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (4 * j < L) v = u32x4{C[h][(4 * j) % L], (4 * j + 1 < L) ? C[h][(4 * j + 1) % L] : 0u,
+                                         (4 * j + 2 < L) ? C[h][(4 * j + 2) % L] : 0u, (4 * j + 3 < L) ? C[h][(4 * j + 3) % L] : 0u};
+                dst[j * 64] = v;
+              }
+            }
+          }
+        }
+        // ---- interval tests of both halves at the half threshold; look up what fails either ----
+        u32 m = (outside(C[0], rdlane(lhv[0], t)) | outside(C[1], rdlane(lhv[1], t))) & valid;
+        if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
+        n_slow++;
+        const double* dp = a.d64 + sp_diag_offset(rdlane(totv[0], t));
+        const double* dn = a.d64 + sp_diag_offset(rdlane(totv[1], t));
+        while (m != 0u) {
+          u32 bb[4];
+          double sp[4], sn[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            bb[k] = m ? (u32)__builtin_ctz(m) : bb[k ? k - 1 : 0];   // exhausted: repeat the last one (max is idempotent)
+            m &= m - 1u;
+            u32 ca = 0u, cb = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              ca |= ((C[0][l] >> bb[k]) & 1u) << l;
+              cb |= ((C[1][l] >> bb[k]) & 1u) << l;
+            }
+            sp[k] = dp[ca];
+            sn[k] = dn[cb];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            float f = (float)(sp[k] + sn[k]);
+            f = (f > 0.0f) ? f : 0.0f;
+            __hip_atomic_fetch_max(nm + bb[k] * 64, __float_as_uint(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+        }
+        dirty = true;
+      }
+    }
+  }
+  flush_tile();
+  if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
+}
+
 // method 2 runs the general kernel; method 1 the specialised one: L from the largest carrier total, GZ = plane groups of
 // the added rows that can be non-zero (<= L/4), OUT = planes of the joined paths wanted
 #define GCRE_IE_M2(EXPR)                    \
@@ -758,6 +1003,11 @@ hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general,
 #define GCRE_LAUNCH(LL, GG, OO, RR) hipLaunchKernelGGL((k_null_ie_m1<LL, GG, OO, RR>), grid, block, 0, stream, a)
     GCRE_IE_M1(GCRE_LAUNCH)
 #undef GCRE_LAUNCH
+  } else if (method == 2 && !general) {
+    const bool out = a.planes_out != nullptr;
+#define GCRE_LAUNCH2(LL) if (out) hipLaunchKernelGGL((k_null_ie_m2<LL, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((k_null_ie_m2<LL, false>), grid, block, 0, stream, a)
+    if (planes <= 8) { GCRE_LAUNCH2(8); } else if (planes <= 10) { GCRE_LAUNCH2(10); } else if (planes <= 12) { GCRE_LAUNCH2(12); } else { GCRE_LAUNCH2(16); }
+#undef GCRE_LAUNCH2
   } else {
 #define GCRE_LAUNCH(MM, LL) hipLaunchKernelGGL((k_null_ie<MM, LL>), grid, block, 0, stream, a)
     GCRE_IE_GEN(GCRE_LAUNCH)
@@ -774,9 +1024,9 @@ int ie_max_waves_per_cu(int method, int planes, int gz, bool out, bool rec) {
     GCRE_IE_M1(GCRE_OCC)
 #undef GCRE_OCC
   } else {
-#define GCRE_OCC(MM, LL) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie<MM, LL>, 64 * kIeWaves, 0)
-    GCRE_IE_M2(GCRE_OCC)
-#undef GCRE_OCC
+#define GCRE_OCC2(LL) e = out ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m2<LL, true>, 64 * kIeWaves, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m2<LL, false>, 64 * kIeWaves, 0)
+    if (planes <= 8) { GCRE_OCC2(8); } else if (planes <= 10) { GCRE_OCC2(10); } else if (planes <= 12) { GCRE_OCC2(12); } else { GCRE_OCC2(16); }
+#undef GCRE_OCC2
   }
   if (e != hipSuccess || blocks < 1) blocks = 1;
   return blocks * kIeWaves;
@@ -912,6 +1162,79 @@ __global__ __launch_bounds__(64) void k_build_ladder(const u32* t32, int TD, u32
 
 hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipStream_t stream) {
   hipLaunchKernelGGL(k_build_ladder, dim3((unsigned)TD), dim3(64), 0, stream, (const u32*)t32, TD, ladder);
+  return hipGetLastError();
+}
+
+// The signed method's ladder: same construction on the f64 vtmax diagonals at HALF the threshold of each level
+// (row j: the interval on which vtmax <= j / (2 * kLadderPerUnit)), see k_null_ie_m2.
+__global__ __launch_bounds__(64) void k_build_ladder2(const double* dmax, int TD, u32* ladder) {
+  __shared__ int left[kLadderLevels + 2], right[kLadderLevels + 2];
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (t >= TD) return;
+  const double* d = dmax + sp_diag_offset((u32)t);
+  for (int k = lane; k < kLadderLevels + 2; k += 64) {
+    left[k] = -1;
+    right[k] = t + 1;
+  }
+  // first minimum of the diagonal
+  double bestv = __builtin_inf();
+  int bestc = 0x7fffffff;
+  for (int c = lane; c <= t; c += 64) {
+    const double v = d[c];
+    if (v < bestv || (v == bestv && c < bestc) || (bestc == 0x7fffffff)) {
+      if (!(v != v)) { bestv = v; bestc = c; }
+      else if (bestc == 0x7fffffff) { bestv = __builtin_inf(); bestc = c; }   // NaN cells never count as a minimum
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(bestv, o, 64);
+    const int oc = __shfl_xor(bestc, o, 64);
+    if (ov < bestv || (ov == bestv && oc < bestc)) { bestv = ov; bestc = oc; }
+  }
+  const int c0 = bestc;
+  __syncthreads();
+  auto blocked_below = [](double v) -> int {   // number of levels whose half threshold j / 16 is below the value
+    if (v != v) return kLadderLevels;          // NaN: never provably small
+    if (!(v > 0.0)) return 0;
+    const double x = v * (double)(2 * kLadderPerUnit);
+    if (x >= (double)kLadderLevels) return kLadderLevels;
+    const int j = (int)x;
+    return ((double)j < x) ? j + 1 : j;
+  };
+  for (int c = lane; c <= t; c += 64) {
+    if (c == c0) continue;
+    const int J = blocked_below(d[c]);
+    if (J == 0) continue;
+    if (c < c0) atomicMax(&left[J], c);
+    else atomicMin(&right[J], c);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int l = -1, r = t + 1;
+    for (int k = kLadderLevels; k >= 0; k--) {
+      l = left[k] > l ? left[k] : l;
+      r = right[k] < r ? right[k] : r;
+      left[k] = l;
+      right[k] = r;
+    }
+  }
+  __syncthreads();
+  const int Jbest = blocked_below(d[c0]);
+  for (int j = lane; j < kLadderLevels; j += 64) {
+    u32 e = 1u;   // lo = 1, hi = 0: empty
+    if (Jbest <= j) e = ((u32)(right[j + 1] - 1) << 16) | (u32)(left[j + 1] + 1);
+    ladder[(size_t)j * TD + t] = e;
+  }
+  if (lane == 0) {
+    ladder[(size_t)kLadderLevels * TD + t] = 0xffff0000u;
+    ladder[(size_t)(kLadderLevels + 1) * TD + t] = 1u;
+  }
+}
+
+hipError_t launch_build_ladder2(const double* dmax, int TD, uint32_t* ladder, hipStream_t stream) {
+  hipLaunchKernelGGL(k_build_ladder2, dim3((unsigned)TD), dim3(64), 0, stream, dmax, TD, ladder);
   return hipGetLastError();
 }
 

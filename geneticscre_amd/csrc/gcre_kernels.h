@@ -140,6 +140,7 @@ int ie_max_waves_per_cu(int method, int planes, int gz, bool out, bool rec);
 hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, const uint64_t* loff, const uint32_t* lidx,
                                int64_t nrowhalves, int groups, uint32_t* planes, hipStream_t stream);
 hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipStream_t stream);
+hipError_t launch_build_ladder2(const double* dmax, int TD, uint32_t* ladder, hipStream_t stream);   // signed method, half thresholds
 // exclusive prefix sum of n u32 counts into n+1 u64 offsets; the low 2 bits of a count do not add, they are copied
 // into the low bits of its offset (list lengths are multiples of 4, bit 0 carries the IE list mode) (scratch: >= (n+1023)/1024 + 1 u64)
 hipError_t launch_scan_u32_u64(const uint32_t* cnt, int64_t n, uint64_t* off, uint64_t* scratch, hipStream_t stream);
