@@ -1513,7 +1513,7 @@ int gcre_set_value_table(gcre_ctx* c, const double* table, int nrow, int ncol, i
   if (e == hipSuccess)
     e = launch_table_to_diag(d_raw, nrow, ncol, col_major, n, (int)TD, c->d_dvt, c->d_t32, c->d_dmax, c->stream);
   if (e == hipSuccess && TD <= 65536) {   // counts fit the 16-bit bounds of a ladder entry
-    if (!c->d_ladder) e = hipMalloc((void**)&c->d_ladder, (size_t)(kLadderLevels + 2) * TD * 4);
+    if (!c->d_ladder) e = hipMalloc((void**)&c->d_ladder, (size_t)(kLadder2Levels + 2) * TD * 4);
     if (e == hipSuccess)
       e = g.method == 1 ? launch_build_ladder(c->d_t32, (int)TD, c->d_ladder, c->stream)
                         : launch_build_ladder2(c->d_dmax, (int)TD, c->d_ladder, c->stream);

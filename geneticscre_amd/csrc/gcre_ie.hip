@@ -716,11 +716,14 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // method 2 (signed), pruned.  A joined path has a (+) and a (-) half with their own counts a, b and carrier totals
-// tp, tn; its null score is (float)(vtmax[tp][a] + vtmax[tn][b]) (methods.h:220-230).  For a threshold theta not
-// above any running maximum of the tile, a permutation with vtmax[tp][a] <= theta/2 AND vtmax[tn][b] <= theta/2
-// cannot raise its maximum (the f64 sum is <= theta, rounding to f32 is monotone), so both halves are tested against
-// the half-threshold intervals of their diagonals (k_build_ladder2) and only permutations that fail either test are
-// looked up -- exactly: both cells gathered in f64, added, rounded, clamped at 0.
+// tp, tn; its null score is (float)(F + G), F = vtmax[tp][a], G = vtmax[tn][b] (methods.h:220-230).  For a threshold
+// theta not above any running maximum of the tile and any split ha + hb <= theta, a permutation with (F <= ha and
+// G <= hb) or (F <= hb and G <= ha) cannot raise its maximum (the f64 sum is <= theta, rounding to f32 is monotone).
+// With ha ~ theta/3, hb ~ 2 theta/3 the two rectangles leave ~3 exp(-2 theta / 3) of the permutations, against
+// 2 exp(-theta / 2) for the single square (theta/2, theta/2): 14 % instead of 93 % of the path-tiles reach a lookup at
+// configs[2] geometry.  Both halves are tested against the intervals of their diagonals for ha and hb
+// (k_build_ladder2, four borrow-chain tests); what fails both rectangles is looked up exactly: both cells gathered in
+// f64, added, rounded, clamped at 0.
 // ------------------------------------------------------------------------------------------------
 template <int L, bool OUT>
 __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
@@ -742,7 +745,9 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
 
   int cur_kt = -1;
   u32 valid = 0u;
-  u32 lad_base = (a.lad_mode == 0) ? 0u : (u32)(kLadderLevels - 1 + a.lad_mode) * (u32)a.ladder_stride;
+  // two ladder rows: thresholds ha + hb <= theta (about theta/3 and 2 theta/3), rows are in units of 1/(2 kLadderPerUnit)
+  u32 lad_a = (a.lad_mode == 0) ? 0u : (u32)(kLadder2Levels - 1 + a.lad_mode) * (u32)a.ladder_stride;
+  u32 lad_b = lad_a;
   bool dirty = false;
   u32 n_slow = 0u;
   __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)a.mt, 0, 0x7fffffff, 0x00020000);
@@ -765,9 +770,13 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
     dirty = false;
     u32 theta = __builtin_amdgcn_readfirstlane(wave_min_u32(lo));
     if (theta == 0xffffffffu) theta = 0u;
-    int j = (int)(__uint_as_float(theta) * (float)kLadderPerUnit);   // ladder row j holds the intervals for theta_j / 2
+    int j = (int)(__uint_as_float(theta) * (float)kLadderPerUnit);   // theta >= j / kLadderPerUnit = 2 j rows
     j = j < 0 ? 0 : (j > kLadderLevels - 1 ? kLadderLevels - 1 : j);
-    lad_base = (u32)j * (u32)a.ladder_stride;
+    const int ra = (2 * j) / 3;
+    int rb = 2 * j - ra;
+    rb = rb > kLadder2Levels - 1 ? kLadder2Levels - 1 : rb;
+    lad_a = (u32)ra * (u32)a.ladder_stride;
+    lad_b = (u32)rb * (u32)a.ladder_stride;
   };
   auto flush_tile = [&]() {
     if (cur_kt >= 0) {
@@ -817,7 +826,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
       mt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mt + (size_t)kt * a.mt_rows * 64), 0, 0x7fffffff, 0x00020000);
       const int live = a.K - kt * 2048 - lane * 32;
       valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
-      if (a.lad_mode == 0) lad_base = 0u;
+      if (a.lad_mode == 0) lad_a = lad_b = 0u;
     }
     int since = 0, period = 1;
     for (i64 sidx = a.seg_begin + sl; sidx < a.seg_end; sidx += slices) {
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
       // ---- per-path metadata of the segment: lane t <-> joined path first + t, both halves ----
       const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
       const u32 rzv = a.rowz[qv];
-      u32 infov[2], lovv[2], zunit[2], totv[2], lhv[2];
+      u32 infov[2], lovv[2], zunit[2], totv[2], lha[2], lhb[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         infov[h] = a.linfo[(u64)qv * 2 + h];
@@ -840,7 +849,8 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
         const u32 hz = (rzv >> 31) ? (u32)(1 - h) : (u32)h;
         zunit[h] = ((u32)kt * (u32)a.rowsz + (rzv & 0x7fffffffu) * 2u + hz) * (u32)a.gz;
         totv[h] = a.tot[(u64)qv * 2 + h];
-        lhv[h] = a.ladder[lad_base + totv[h]];
+        lha[h] = a.ladder[lad_a + totv[h]];
+        lhb[h] = a.ladder[lad_b + totv[h]];
       }
       const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 16u);
       u32 B[2][LP];
@@ -922,8 +932,10 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
             }
           }
         }
-        // ---- interval tests of both halves at the half threshold; look up what fails either ----
-        u32 m = (outside(C[0], rdlane(lhv[0], t)) | outside(C[1], rdlane(lhv[1], t))) & valid;
+        // ---- a permutation is safe when (F <= ha and G <= hb) or (F <= hb and G <= ha): ha + hb <= theta ----
+        const u32 pa = outside(C[0], rdlane(lha[0], t)), pb = outside(C[0], rdlane(lhb[0], t));
+        const u32 na = outside(C[1], rdlane(lha[1], t)), nb_ = outside(C[1], rdlane(lhb[1], t));
+        u32 m = (pa | nb_) & (pb | na) & valid;
         if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
         n_slow++;
         const double* dp = a.d64 + sp_diag_offset(rdlane(totv[0], t));
@@ -1166,14 +1178,14 @@ hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipSt
 }
 
 // The signed method's ladder: same construction on the f64 vtmax diagonals at HALF the threshold of each level
-// (row j: the interval on which vtmax <= j / (2 * kLadderPerUnit)), see k_null_ie_m2.
+// (row r: the interval on which vtmax <= r / (2 * kLadderPerUnit), kLadder2Levels rows), see k_null_ie_m2.
 __global__ __launch_bounds__(64) void k_build_ladder2(const double* dmax, int TD, u32* ladder) {
-  __shared__ int left[kLadderLevels + 2], right[kLadderLevels + 2];
+  __shared__ int left[kLadder2Levels + 2], right[kLadder2Levels + 2];
   const int t = blockIdx.x;
   const int lane = threadIdx.x;
   if (t >= TD) return;
   const double* d = dmax + sp_diag_offset((u32)t);
-  for (int k = lane; k < kLadderLevels + 2; k += 64) {
+  for (int k = lane; k < kLadder2Levels + 2; k += 64) {
     left[k] = -1;
     right[k] = t + 1;
   }
@@ -1196,10 +1208,10 @@ __global__ __launch_bounds__(64) void k_build_ladder2(const double* dmax, int TD
   const int c0 = bestc;
   __syncthreads();
   auto blocked_below = [](double v) -> int {   // number of levels whose half threshold j / 16 is below the value
-    if (v != v) return kLadderLevels;          // NaN: never provably small
+    if (v != v) return kLadder2Levels;          // NaN: never provably small
     if (!(v > 0.0)) return 0;
     const double x = v * (double)(2 * kLadderPerUnit);
-    if (x >= (double)kLadderLevels) return kLadderLevels;
+    if (x >= (double)kLadder2Levels) return kLadder2Levels;
     const int j = (int)x;
     return ((double)j < x) ? j + 1 : j;
   };
@@ -1213,7 +1225,7 @@ __global__ __launch_bounds__(64) void k_build_ladder2(const double* dmax, int TD
   __syncthreads();
   if (lane == 0) {
     int l = -1, r = t + 1;
-    for (int k = kLadderLevels; k >= 0; k--) {
+    for (int k = kLadder2Levels; k >= 0; k--) {
       l = left[k] > l ? left[k] : l;
       r = right[k] < r ? right[k] : r;
       left[k] = l;
@@ -1222,14 +1234,14 @@ __global__ __launch_bounds__(64) void k_build_ladder2(const double* dmax, int TD
   }
   __syncthreads();
   const int Jbest = blocked_below(d[c0]);
-  for (int j = lane; j < kLadderLevels; j += 64) {
+  for (int j = lane; j < kLadder2Levels; j += 64) {
     u32 e = 1u;   // lo = 1, hi = 0: empty
     if (Jbest <= j) e = ((u32)(right[j + 1] - 1) << 16) | (u32)(left[j + 1] + 1);
     ladder[(size_t)j * TD + t] = e;
   }
   if (lane == 0) {
-    ladder[(size_t)kLadderLevels * TD + t] = 0xffff0000u;
-    ladder[(size_t)(kLadderLevels + 1) * TD + t] = 1u;
+    ladder[(size_t)kLadder2Levels * TD + t] = 0xffff0000u;
+    ladder[(size_t)(kLadder2Levels + 1) * TD + t] = 1u;
   }
 }
 

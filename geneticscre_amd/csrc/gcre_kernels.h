@@ -91,6 +91,7 @@ int sparse_max_waves_per_cu(int method, int planes);   // resident waves per CU 
 // ---- inclusion-exclusion null kernel on count planes (gcre_ie.hip) ----
 constexpr int kLadderLevels = 256;   // pruning thresholds j / kLadderPerUnit, j = 0 .. kLadderLevels-1
 constexpr int kLadderPerUnit = 8;
+constexpr int kLadder2Levels = 352;  // signed method: rows r <-> threshold r / (2 kLadderPerUnit), up to 4/3 of the method-1 range
 struct IeArgs {
   const uint32_t* mt;        // transposed masks, as SparseArgs
   const uint32_t* tot;       // carriers per joined path (and half) of the launch
