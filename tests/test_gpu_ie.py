@@ -266,3 +266,32 @@ def test_recipes_replace_stored_planes(limit_mb, world, monkeypatch):
         w = want[f"lst{lvl}"]
         np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
         np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
+
+
+@pytest.mark.parametrize("method,seed", [("method1", 101), ("method1", 102), ("method2", 103)])
+def test_three_kernel_forms_agree_at_scale(method, seed, monkeypatch):
+    """Beyond what the CPU oracle finishes in seconds: 10^6 joined paths x 2,500 permutations, a hub gene
+    included, scored by the IE kernels (with recipes), the delta-streaming kernel and the dense AND+popcount kernel.
+    Three independent formulations of the same counts must return bit-identical results."""
+    rng = np.random.default_rng(seed)
+    p = make_problem(400, 3000, 330, 350, 2500, 5, method=method, top_k=40, seed=seed, threshold=0.05)
+    hub = int(np.bincount(p.levels.uids["2"].count.astype(np.int64) > 0).argmax())   # any gene; its row becomes dense-ish
+    p.data1[hub] = (rng.random(p.data1.shape[1]) < 0.04).astype(np.int32)
+    p.data2 = p.data1[p.levels.uids["1b"].src]
+    results = {}
+    for form, env in (("ie", {"GCRE_NULL_KERNEL": "ie", "GCRE_PLANES_OUT_MAX_MB": "0"}),
+                      ("sparse", {"GCRE_NULL_KERNEL": "sparse"}), ("dense", {"GCRE_NULL_KERNEL": "dense"})):
+        for k in ("GCRE_NULL_KERNEL", "GCRE_PLANES_OUT_MAX_MB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        results[form] = api.process_paths(p)
+    assert sum(p.levels.n_paths[k] for k in ("4", "5")) > 500000
+    for lvl in range(1, 6):
+        a = results["dense"][f"lst{lvl}"]
+        for form in ("ie", "sparse"):
+            b = results[form][f"lst{lvl}"]
+            np.testing.assert_array_equal(a.null.view(np.uint32), b.null.view(np.uint32), err_msg=f"{form} L{lvl} null")
+            np.testing.assert_array_equal(a.scores.view(np.uint64), b.scores.view(np.uint64), err_msg=f"{form} L{lvl}")
+            np.testing.assert_array_equal(a.src, b.src)
+            np.testing.assert_array_equal(a.trg, b.trg)
