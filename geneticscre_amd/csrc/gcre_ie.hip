@@ -1294,13 +1294,21 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
   bool my_bad = false;
   constexpr u32 kOverChunk = 2048;   // entries of the overflow area a wave reserves at a time
   u32 chunk_at = 0u, chunk_left = 0u;
+  // the row numbers of the next group of four paths (two dependent loads) are fetched while this one is worked on
+  auto fetch = [&](i64 base, u32& r0, u32& r1raw, u32& zraw, u32& rng) {
+    const i64 i = (base + (lane >> 4) < a.count) ? base + (lane >> 4) : a.count - 1;
+    r0 = a.row0[i];
+    r1raw = a.row1[i];
+    zraw = a.zindex ? (u32)a.zindex[r1raw & 0x7fffffffu] : (r1raw & 0x7fffffffu);
+    rng = a.excess ? (u32)a.range_of[r0] : 0u;
+  };
+  u32 n_r0 = 0, n_r1raw = 0, n_zraw = 0, n_rng = 0;
+  if (wave * 4 < a.count) fetch(wave * 4, n_r0, n_r1raw, n_zraw, n_rng);
   for (i64 base = wave * 4; base < a.count; base += nwaves * 4) {
     const bool active = base + (lane >> 4) < a.count;
     const i64 i = active ? base + (lane >> 4) : a.count - 1;   // idle rows shadow the last path and write nothing
-    const u32 r0 = a.row0[i];
-    const u32 r1raw = a.row1[i];
-    const u32 r1 = r1raw & 0x7fffffffu;
-    const u32 zraw = a.zindex ? (u32)a.zindex[r1] : r1;
+    const u32 r0 = n_r0, r1raw = n_r1raw, zraw = n_zraw, rng = n_rng;
+    if (base + nwaves * 4 < a.count) fetch(base + nwaves * 4, n_r0, n_r1raw, n_zraw, n_rng);
     const u32 rz = zraw & 0x7fffffffu;
     const u32 zflip = (r1raw ^ (a.zindex ? zraw : 0u)) & 0x80000000u;
     const u64* x = a.p0 + (size_t)r0 * a.S;
@@ -1309,7 +1317,7 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
     // without a hint z IS paths1[loc]; with one, paths1[loc] = z | excess (k_range_union checked z inside it) and
     // the union U of the excess over every row this uid joins must lie inside paths0[idx] -- checked below -- so
     // paths0[idx] | paths1[loc] == paths0[idx] | z for every path of the uid.
-    const u64* uu = a.excess ? a.excess + (size_t)a.range_of[r0] * a.S : nullptr;
+    const u64* uu = a.excess ? a.excess + (size_t)rng * a.S : nullptr;
     u64* out = (a.res && active) ? a.res + (size_t)(a.first + i) * a.S : nullptr;
     const bool swap = (M == 2) && (r1raw >> 31) != 0;
     const u64* uh[2] = {(uu && swap) ? uu + Wp : uu, (uu && !swap) ? uu + Wp : uu};
