@@ -194,6 +194,7 @@ struct gcre_uids {
   // optional hint (gcre_uids_set_reduced): paths0[idx] | paths1[loc] == paths0[idx] | red[red_index[loc]] for every
   // joined path; checked on the device for every join, ignored when it does not hold
   const gcre_pathset* red = nullptr;
+  uint64_t red_id = 0;             // the set's id: a freed operand is noticed, not dereferenced
   int32_t* d_red_index = nullptr;
   int64_t n_red_index = 0;
   // distinct (location, count) ranges of the uids (all uids with the same pivot gene share one): built on first use
@@ -821,7 +822,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     const bool sparse_ok = sparse_enabled(c) && w_mt != nullptr;
     bool want_ie = sparse_ok && (c->null_kernel == 0 || c->null_kernel == 3);
     const int nkt_sp = (g.K + kSparseTile - 1) / kSparseTile;
-    bool hinted = want_ie && u.red && u.red->ctx == c && u.d_red_index && u.n_red_index > u.max_loc;
+    bool hinted = false;
+    if (want_ie && u.red && u.d_red_index && u.n_red_index > u.max_loc) {
+      auto it = c->live_sets.find(u.red_id);   // the caller may have freed the operand since
+      hinted = it != c->live_sets.end() && it->second == u.red;
+    }
     const gcre_pathset* red = nullptr;
     bool have_pz = false, have_p0 = false, res_planes = false, res_planes_ok = false, use_rec = false;
     const gcre_pathset *rec_a = nullptr, *rec_z = nullptr;
@@ -1830,6 +1835,7 @@ int gcre_uids_set_reduced(gcre_uids* u, const gcre_pathset* reduced, const int32
   HIP_TRY(c, hipMemcpyAsync(u->d_red_index, index, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   u->red = reduced;
+  u->red_id = reduced->id;
   u->n_red_index = n;
   return GCRE_OK;
 }

@@ -295,3 +295,27 @@ def test_three_kernel_forms_agree_at_scale(method, seed, monkeypatch):
             np.testing.assert_array_equal(a.scores.view(np.uint64), b.scores.view(np.uint64), err_msg=f"{form} L{lvl}")
             np.testing.assert_array_equal(a.src, b.src)
             np.testing.assert_array_equal(a.trg, b.trg)
+
+
+def test_freed_reduced_operand_is_not_used(monkeypatch):
+    """A hint whose operand was freed in the meantime is dropped (the set is looked up by id, never dereferenced)."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    p = sparse_problem("method1", 15, K=150, L=4)
+    full = oracle.process_paths(p, order="canonical")
+    ex = api.JoinExec("method1", p.n_cases, p.n_ctrls, p.iterations)
+    ex.top_k = p.top_k
+    ex.set_value_table(p.value_table)
+    ex.set_permuted_cases(p.perm_cases)
+    p3, p2 = ex.from_words(full["paths3"]), ex.from_words(full["paths2"])
+    genes = ex.load(p.data1)
+    du = api.DeviceUids(ex, p.levels.uids["4"])
+    du.set_reduced(genes, p.levels.data_inds["3"])
+    assert_same_result(ex.join(du, p3, p2), full["lst4"])
+    assert ex.profile()["ie_hinted_joins"] == 1
+    genes.free()
+    du._reduced = None
+    junk = ex.create_path_set(genes.size)          # may well land where the freed set lived
+    assert_same_result(ex.join(du, p3, p2), full["lst4"])
+    assert ex.profile()["ie_hinted_joins"] == 0
+    junk.free()
+    ex.close()
