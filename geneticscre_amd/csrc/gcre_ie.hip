@@ -458,6 +458,23 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       // through the scalar cache, one s_load_dwordx8 per path, fetched one path ahead of the loads that use them
       typedef u32 __attribute__((ext_vector_type(8))) u32x8;
       const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 8u);
+      auto issue = [&](u32 t2, const u32x8 offs, u32 (&yy)[8], u32 (&ZZ)[4 * GZ]) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+        const u32x4* src = (const u32x4*)(a.planesz + (u64)rdlane(zunit, t2) * 256u) + lane;
+#pragma unroll
+        for (int j = 0; j < GZ; j++) {
+          const u32x4 v = src[j * 64];
+          ZZ[4 * j + 0] = v.x; ZZ[4 * j + 1] = v.y; ZZ[4 * j + 2] = v.z; ZZ[4 * j + 3] = v.w;
+        }
+      };
+      // the first path's loads do not depend on the base counters: they go out before those are read (and, with a
+      // recipe, rebuilt), one round trip earlier
+      u32 yA[8], yB[8], ZA[4 * GZ], ZB[4 * GZ];
+      const u32 last = npaths - 1u;
+      auto at = [&](u32 t2) -> u32 { return t2 < last ? t2 : last; };
+      u32x8 oA = slots[0], oB = slots[at(1u)];
+      issue(0u, oA, yA, ZA);
       // ---- base counters: the planes of paths0[row0] -- stored, or (REC) rebuilt from the recipe of the join that
       // produced the row: planes of ITS paths0 row + planes of the row it added -/+ its 8-entry list ----
       u32 B[LP];
@@ -536,16 +553,6 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       // ---- the joined paths of the segment, software-pipelined one path ahead: the 8 mask rows and the planes of
       // path t+1 are in flight while path t is computed.  Loads are issued unconditionally (the last path is simply
       // requested twice) so that the compiler's counters let the older loads retire without draining the younger.
-      auto issue = [&](u32 t2, const u32x8 offs, u32 (&yy)[8], u32 (&ZZ)[4 * GZ]) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
-        const u32x4* src = (const u32x4*)(a.planesz + (u64)rdlane(zunit, t2) * 256u) + lane;
-#pragma unroll
-        for (int j = 0; j < GZ; j++) {
-          const u32x4 v = src[j * 64];
-          ZZ[4 * j + 0] = v.x; ZZ[4 * j + 1] = v.y; ZZ[4 * j + 2] = v.z; ZZ[4 * j + 3] = v.w;
-        }
-      };
       auto compute = [&](u32 t, const u32 (&y)[8], const u32 (&Z)[4 * GZ]) {
         GCRE_TM_MARK(tp0);
         const u32 r0 = rdlane(infov, t);
@@ -688,11 +695,6 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
         GCRE_TM_ADD(3, tp3, tp2);
       };
 
-      u32 yA[8], yB[8], ZA[4 * GZ], ZB[4 * GZ];
-      const u32 last = npaths - 1u;
-      auto at = [&](u32 t2) -> u32 { return t2 < last ? t2 : last; };
-      u32x8 oA = slots[0], oB = slots[at(1u)];
-      issue(0u, oA, yA, ZA);
       for (u32 t = 0; t < npaths; t += 2) {
         issue(at(t + 1), oB, yB, ZB);
         oA = slots[at(t + 2)];
