@@ -46,8 +46,16 @@ def build_inputs(cfg, seed, top_k):
     n = cfg["cases"] + cfg["ctrls"]
     data1 = synth.variant_matrix(g, n, rng)
     data2 = data1[levels.uids["1b"].src]
-    table = synth.values_table(cfg["cases"], cfg["ctrls"])
-    masks = synth.packed_case_masks(cfg["cases"], cfg["ctrls"], cfg["perms"], rng)
+    big = n * cfg["perms"] > 2_000_000_000 or n > 20000
+    if big:
+        # configs[3]/[4] scale: the numpy table builder is O(n m^2) and the host mask generator minutes -- use the native
+        # table builder (gcre_values_table, no GPU needed) and let the device draw the masks (gcre_generate_perm_masks)
+        from geneticscre_amd import api
+        table = api.values_table(cfg["cases"], cfg["ctrls"])
+        masks = None
+    else:
+        table = synth.values_table(cfg["cases"], cfg["ctrls"])
+        masks = synth.packed_case_masks(cfg["cases"], cfg["ctrls"], cfg["perms"], rng)
     prob = synth.Problem(cfg["method"], cfg["cases"], cfg["ctrls"], cfg["length"], top_k, cfg["perms"], levels,
                          data1, data2, table, np.zeros((0, 0), np.int32), seed)
     return prob, masks
@@ -224,7 +232,7 @@ def main():
 
     from geneticscre_amd import api
     from geneticscre_amd.dist import exchange_level
-    plan = api.ResidentPlan(prob, device=local_rank, packed_masks=masks)
+    plan = api.ResidentPlan(prob, device=local_rank, packed_masks=masks, mask_seed=args.seed if masks is None else None)
     K, top_k = prob.iterations, prob.top_k
     d_null = torch.zeros(max(K, 1), dtype=torch.float32, device=dev)
     prof_acc = {}
@@ -314,7 +322,7 @@ def main():
             per_tile = valu / ref_tiles if valu > 0 else per_tile
         peak = 256 * 4 * 2.4e9 / 4.0            # wave64 VALU instructions per second the chip can issue
         ach = per_tile * tiles * args.steps / null_s if null_s > 0 else 0.0
-        roofline["kernel"] = "k_null_ie_m1 (+ warm-up slice on k_null_ie)"
+        roofline["kernel"] = "%s (+ warm-up slice on k_null_ie)" % ("k_null_ie_m2" if prob.method == "method2" else "k_null_ie_m1")
         roofline["note"] = ("north-star accounting (algorithmic HBM bytes / kernel time); the kernel is bound by VALU issue, "
                             "see valu; `launches` counts joins (one warm-up + one pruned launch each)")
         roofline["valu"] = {"achieved": ach, "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
@@ -354,7 +362,9 @@ def main():
         "ie": {k: int(prof_acc.get(k, 0)) // args.steps for k in
                ("ie_launches", "ie_overlap_lists", "ie_hinted_joins", "ie_plane_joins", "ie_lookup_tiles")},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and masks is None:
+        line["cpu_baseline"] = {"skipped": "device-drawn masks at this scale; the baseline is timed on configs[2]"}
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(prob, masks)
         except Exception as e:   # the baseline is reported, never required

@@ -530,14 +530,17 @@ class ResidentPlan:
 
     LEVELS = ["1a", "1b", "2", "3", "4", "5"]
 
-    def __init__(self, problem, device: int = 0, packed_masks: Optional[np.ndarray] = None):
+    def __init__(self, problem, device: int = 0, packed_masks: Optional[np.ndarray] = None,
+                 mask_seed: Optional[int] = None):
         self.problem = problem
         self._needed: Dict[tuple, Tuple[int, int]] = {}
         self._window: Optional[int] = None
         ex = self.ex = JoinExec(problem.method, problem.n_cases, problem.n_ctrls, problem.iterations, device)
         ex.top_k = problem.top_k
         ex.set_value_table(problem.value_table)
-        if packed_masks is not None:
+        if mask_seed is not None:
+            ex.generate_permutations(mask_seed)      # drawn on the device: every rank with the same seed gets the same masks
+        elif packed_masks is not None:
             ex.set_permuted_masks(packed_masks)
         else:
             ex.set_permuted_cases(problem.perm_cases)
