@@ -46,7 +46,7 @@ def build_inputs(cfg, seed, top_k):
     n = cfg["cases"] + cfg["ctrls"]
     data1 = synth.variant_matrix(g, n, rng)
     data2 = data1[levels.uids["1b"].src]
-    big = n * cfg["perms"] > 2_000_000_000 or n > 20000
+    big = n * cfg["perms"] > 2_000_000_000 or n > 20000 or cfg["perms"] > 20000
     if big:
         # configs[3]/[4] scale: the numpy table builder is O(n m^2) and the host mask generator minutes -- use the native
         # table builder (gcre_values_table, no GPU needed) and let the device draw the masks (gcre_generate_perm_masks)

@@ -189,7 +189,7 @@ struct gcre_uids {
   int32_t* d_signs;
   std::vector<int64_t> h_path_idx;   // host copy, for building the sparse kernel's segment tables
   std::vector<int64_t> h_location;   // host copy: segments are ordered by the paths1 rows they join (L2 reuse of their planes)
-  struct SegCache { int64_t first, count; int64_t nsegs; SparseSeg* d_segs; };
+  struct SegCache { int64_t first, count, score_b, score_e; int64_t nsegs, nscored; SparseSeg* d_segs; };
   mutable std::vector<SegCache> seg_cache;
   // optional hint (gcre_uids_set_reduced): paths0[idx] | paths1[loc] == paths0[idx] | red[red_index[loc]] for every
   // joined path; checked on the device for every join, ignored when it does not hold
@@ -474,47 +474,58 @@ int ensure_planes(gcre_ctx* c, const gcre_pathset* ps) {
 }
 
 // Segment table of the joined paths [first, first+count): runs of paths that share their paths0 row, at most
-// kSparseSegMax long.  Cached per uids object (the join index is resident input; repeated joins reuse it).
-int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t count, const SparseSeg** d_out,
-                    int64_t* nsegs) {
+// kSparseSegMax long, none straddling the scored range [score_b, score_e).  The scored segments come first
+// (*nscored of them).  Cached per uids object (the join index is resident input; repeated joins reuse it).
+int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t count, int64_t score_b, int64_t score_e,
+                    const SparseSeg** d_out, int64_t* nsegs, int64_t* nscored) {
   for (const auto& sc : u.seg_cache)
-    if (sc.first == first && sc.count == count) {
+    if (sc.first == first && sc.count == count && sc.score_b == score_b && sc.score_e == score_e) {
       *d_out = sc.d_segs;
       *nsegs = sc.nsegs;
+      *nscored = sc.nscored;
       return GCRE_OK;
     }
   HostTimer ht("sparse_segments");
-  std::vector<SparseSeg> segs;
+  std::vector<SparseSeg> segs, rest;
   const auto& pi = u.h_path_idx;
   const int64_t end = first + count;
   // first uid whose range reaches past `first`
   int64_t i = std::upper_bound(pi.begin(), pi.end(), first) - pi.begin() - 1;
   for (; i < u.n_uids && pi[(size_t)i] < end; i++) {
-    int64_t lo = std::max(pi[(size_t)i], first), hi = std::min(pi[(size_t)i + 1], end);
-    for (; lo < hi; lo += kSparseSegMax)
-      segs.push_back(SparseSeg{(uint32_t)i, (uint32_t)(lo - first), (uint32_t)std::min<int64_t>(kSparseSegMax, hi - lo)});
+    const int64_t lo = std::max(pi[(size_t)i], first), hi = std::min(pi[(size_t)i + 1], end);
+    // the uid's paths before, inside and after the scored range
+    const int64_t cut[4] = {lo, std::min(std::max(score_b, lo), hi), std::min(std::max(score_e, lo), hi), hi};
+    for (int part = 0; part < 3; part++) {
+      std::vector<SparseSeg>& dst = (part == 1) ? segs : rest;
+      for (int64_t a = cut[part]; a < cut[part + 1]; a += kSparseSegMax)
+        dst.push_back(SparseSeg{(uint32_t)i, (uint32_t)(a - first), (uint32_t)std::min<int64_t>(kSparseSegMax, cut[part + 1] - a)});
+    }
   }
+  const size_t n_scored = segs.size();
   // Segments that join the same paths1 rows (all uids with the same pivot gene share `location`) run next to each
   // other: the waves of an XCD walk a contiguous window of this table, so the planes of those rows stay in its L2.
   // Any order gives the same maxima.
-  {
+  auto by_location = [&](std::vector<SparseSeg>& v) {
     // a stable counting sort on `location` (rows of paths1: dense keys) -- a comparison sort of millions of
     // segments is a noticeable part of a one-shot gcre_process_paths call
     int64_t max_loc = 0;
-    for (const SparseSeg& sg : segs) max_loc = std::max(max_loc, u.h_location[sg.row0]);
-    if (!segs.empty() && max_loc < (int64_t)64 * (int64_t)segs.size() + 1024) {
+    for (const SparseSeg& sg : v) max_loc = std::max(max_loc, u.h_location[sg.row0]);
+    if (!v.empty() && max_loc < (int64_t)64 * (int64_t)v.size() + 1024) {
       std::vector<uint32_t> start((size_t)max_loc + 2, 0);
-      for (const SparseSeg& sg : segs) start[(size_t)u.h_location[sg.row0] + 1]++;
+      for (const SparseSeg& sg : v) start[(size_t)u.h_location[sg.row0] + 1]++;
       for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
-      std::vector<SparseSeg> sorted(segs.size());
-      for (const SparseSeg& sg : segs) sorted[start[(size_t)u.h_location[sg.row0]]++] = sg;
-      segs.swap(sorted);
+      std::vector<SparseSeg> sorted(v.size());
+      for (const SparseSeg& sg : v) sorted[start[(size_t)u.h_location[sg.row0]]++] = sg;
+      v.swap(sorted);
     } else {
-      std::stable_sort(segs.begin(), segs.end(), [&](const SparseSeg& x, const SparseSeg& y) {
+      std::stable_sort(v.begin(), v.end(), [&](const SparseSeg& x, const SparseSeg& y) {
         return u.h_location[x.row0] < u.h_location[y.row0];
       });
     }
-  }
+  };
+  by_location(segs);
+  by_location(rest);
+  segs.insert(segs.end(), rest.begin(), rest.end());
   SparseSeg* d = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d, std::max<size_t>(segs.size(), 1) * sizeof(SparseSeg)));
   if (!segs.empty())
@@ -524,43 +535,32 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
     (void)hipFree(u.seg_cache.front().d_segs);
     u.seg_cache.erase(u.seg_cache.begin());
   }
-  u.seg_cache.push_back({first, count, (int64_t)segs.size(), d});
+  u.seg_cache.push_back({first, count, score_b, score_e, (int64_t)segs.size(), (int64_t)n_scored, d});
   *d_out = d;
   *nsegs = (int64_t)segs.size();
+  *nscored = (int64_t)n_scored;
   return GCRE_OK;
 }
 
 // ---- top-k selection of one scored chunk: indices of the best min(k, valid) keys, ties cut in index order ----
-int select_chunk(gcre_ctx* c, int64_t count, int k, uint32_t* n_selected) {
+int select_chunk(gcre_ctx* c, int64_t first, int64_t count, int k, uint32_t* n_selected) {
   *n_selected = 0;
   if (count == 0 || k <= 0) return GCRE_OK;
   HIP_TRY(c, c->d_small.reserve(512));
   HIP_TRY(c, c->d_sel.reserve((size_t)k + 64));
   uint32_t* d_hist = c->d_small.p;
   uint32_t* d_counter = c->d_small.p + 256;
-  const uint64_t* key = c->d_key.p;
+  const uint64_t* key = c->d_key.p + first;   // selected indices are relative to `first`
 
-  uint64_t prefix = 0;
-  int64_t need = std::min<int64_t>(k, count);
-  int64_t greater = 0;
-  uint32_t eq_count = 0;
-  uint32_t h[256];
-  for (int shift = 56; shift >= 0; shift -= 8) {
-    HIP_TRY(c, hipMemsetAsync(d_hist, 0, 256 * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, launch_hist(key, count, shift, prefix, d_hist, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(h, d_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    int64_t cum = 0;
-    int b = 255;
-    for (; b > 0; b--) {
-      if (cum + h[b] >= need) break;
-      cum += h[b];
-    }
-    greater += cum;
-    need -= cum;
-    eq_count = h[b];
-    prefix = (prefix << 8) | (uint64_t)b;
-  }
+  // eight digit passes queued back to back; one read-back of the state they leave (gcre_kernels.hip)
+  SelectState* d_state = (SelectState*)(c->d_small.p + 264);
+  SelectState hs{};
+  HIP_TRY(c, launch_radix_select(key, count, std::min<int64_t>(k, count), d_hist, d_state, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&hs, d_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const uint64_t prefix = hs.prefix;
+  const int64_t need = hs.need, greater = hs.greater;
+  const uint32_t eq_count = hs.eq_count;
   const uint64_t T = prefix;   // the need-th largest key overall
   HIP_TRY(c, hipMemsetAsync(d_counter, 0, sizeof(uint32_t), c->stream));
   uint32_t nsel = 0;
@@ -779,8 +779,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   uint32_t keep_max_tot = 0;
 
   if (P > 0) {
-    // segments: rows outside the shard are only materialised (when kept); the shard is scored
-    struct Seg { int64_t b, e; bool score; };
+    // segments: rows outside the shard are only materialised (when kept); the shard [sb, se) inside a segment is scored.
+    // Kept rows next to the shard share its launches (one inspector pass, one flag read-back, one kernel that scores
+    // the shard's path runs and only writes count planes / recipe entries for the others).
+    struct Seg { int64_t b, e, sb, se; };
     std::vector<Seg> segs;
     // kept rows outside the scored shard: all of them, or only [keep_begin, keep_end) (gcre_join_opts.keep_ranged)
     int64_t kb = 0, ke = P;
@@ -788,9 +790,19 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       kb = std::max<int64_t>(0, std::min(jp.keep_begin, P));
       ke = std::max(kb, std::min(jp.keep_end, P));
     }
-    if (keep && kb < std::min(sb, ke)) segs.push_back({kb, std::min(sb, ke), false});
-    if (se > sb) segs.push_back({sb, se, true});
-    if (keep && std::max(se, kb) < ke) segs.push_back({std::max(se, kb), ke, false});
+    if (!keep || kb >= ke) {
+      if (se > sb) segs.push_back({sb, se, sb, se});
+    } else if (se <= sb) {
+      segs.push_back({kb, ke, kb, kb});
+    } else if (kb <= se && sb <= ke) {   // overlapping or adjacent: one segment
+      segs.push_back({std::min(kb, sb), std::max(ke, se), sb, se});
+    } else if (ke < sb) {
+      segs.push_back({kb, ke, kb, kb});
+      segs.push_back({sb, se, sb, se});
+    } else {
+      segs.push_back({sb, se, sb, se});
+      segs.push_back({kb, ke, kb, kb});
+    }
 
     const int64_t tile = cfg.path_tile;
     const int64_t chunk_cap = std::max<int64_t>(tile, (c->chunk_paths / tile) * tile);
@@ -918,9 +930,21 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       }
     }
     c->prof.prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
+    // only the inclusion-exclusion kernels score part of a chunk; every other form gets chunks cut at the shard's ends
+    bool split = !(want_ie && g.K > 0);
     for (const Seg& sg : segs) {
-      for (int64_t cb = sg.b; cb < sg.e; cb += chunk_cap) {
-        const int64_t n = std::min(chunk_cap, sg.e - cb);
+      int64_t next = sg.b;
+      while (next < sg.e) {
+        const int64_t cb = next;
+        int64_t ce = std::min(cb + chunk_cap, sg.e);
+        if (split && cb < sg.sb) ce = std::min(ce, sg.sb);
+        else if (split && cb < sg.se) ce = std::min(ce, sg.se);
+        next = ce;
+        const int64_t n = ce - cb;
+        const int64_t s0 = std::min(std::max<int64_t>(sg.sb - cb, 0), n);       // scored paths of this chunk: [s0, s1)
+        const int64_t s1 = std::max(s0, std::min(std::max<int64_t>(sg.se - cb, 0), n));
+        const bool scored = s1 > s0;
+        const bool partial = scored && (s0 > 0 || s1 < n);
         const int64_t npt = (n + tile - 1) / tile;
         const int64_t padded = npt * tile;
         // the null kernel reads whole tiles: rows / totals beyond n must be valid (row 0, zero carriers)
@@ -949,8 +973,13 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         sa.count = n;
         sa.S = g.S;
         sa.Wp = g.Wp;
-        const bool use_ie = want_ie && (sg.score || res_planes || rcp != nullptr);
-        const bool use_sparse = sg.score && sparse_ok && !want_ie;
+        const bool use_ie = want_ie && (scored || res_planes || rcp != nullptr);
+        const bool use_sparse = scored && sparse_ok && !want_ie;
+        if (partial && !use_ie && g.K > 0) {   // the join left the inclusion-exclusion form on an earlier chunk
+          split = true;
+          next = cb;
+          continue;
+        }
         if (use_sparse || use_ie) {
           collect_ie_stat();
           // flags of this chunk; the long-list counter (word 4) runs on across the chunks of a join that keeps a recipe
@@ -998,7 +1027,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         }
         HIP_TRY(c, hipEventRecord(e1, st));
         c->ev_stats.emplace_back(e0, e1);
-        if (!sg.score && !(use_ie && g.K > 0)) continue;
+        if (!scored && !(use_ie && g.K > 0)) continue;
 
         bool ran_sparse = false, redo = false;
         if (g.K > 0 && use_ie) do {
@@ -1031,7 +1060,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             break;
           }
           const int64_t nseg_est = std::max<int64_t>(uids_in(cb, n), 1);
-          if (c->null_kernel == 0 && sg.score) {
+          if (c->null_kernel == 0 && scored) {
             // auto: dense bit vectors (or tiny K) are cheaper on the AND+BCNT kernel (DESIGN.md "Kernel choice")
             const double base = have_p0 ? 0.0 : (double)row_max(c, jp.p0) * g.method * (double)nseg_est / (double)n;
             const double entries = (double)n_list / (double)n + base + 10.0 * g.method;
@@ -1039,14 +1068,15 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             const double dense_cost = 2.0 * g.Wp * g.method * (double)g.K * 2.0 / 65.0;
             if (ie_cost >= dense_cost) { res_planes_ok = false; break; }
           }
-          if (!sg.score && !res_planes) {   // rows of another shard that only needed their recipe entries
+          if (!scored && !res_planes) {   // rows of another shard that only needed their recipe entries
             ran_sparse = true;
             break;
           }
           int planes = 5;
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           IeArgs ia{};
-          if (int rc = sparse_segments(c, u, cb, n, &ia.segs, &ia.nsegs)) return rc;
+          int64_t nseg_scored = 0;
+          if (int rc = sparse_segments(c, u, cb, n, cb + s0, cb + s1, &ia.segs, &ia.nsegs, &nseg_scored)) return rc;
           ia.mt = w_mt;
           ia.tot = c->d_tot.p;
           ia.rowz = rcp ? rcp->rowz.p + cb : c->d_rowz.p;
@@ -1082,13 +1112,14 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.d64 = c->d_dmax;
           ia.ladder = c->d_ladder;
           ia.ladder_stride = g.TD;
-          ia.lad_mode = !sg.score ? 1 : (c->ie_prune ? 0 : 2);
+          ia.lad_mode = !scored ? 1 : (c->ie_prune ? 0 : 2);
           ia.null_bits = w_null;
           ia.planes_out = res_planes ? jp.res->d_planes : nullptr;
           ia.go = res_planes ? jp.res->plane_groups : 0;
           ia.out_first = cb;
-          ia.score_begin = 0;
-          ia.score_end = sg.score ? (uint32_t)n : 0u;
+          ia.score_begin = (uint32_t)s0;
+          ia.score_end = (uint32_t)s1;
+          ia.score_segs = (uint32_t)nseg_scored;
           ia.nkt = nkt_sp;
           ia.K = g.K;
           ia.mt_rows = (uint32_t)(64 * g.Wp + 1);
@@ -1127,11 +1158,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (c->d_ladder && ia.lad_mode == 0) {
             // warm-up: the first segments are scored without pruning (every count looked up, general kernel); what
             // they find seeds the thresholds the pruned kernel starts from.  Joins of a few thousand paths run here whole.
-            const int64_t n_warm = std::min<int64_t>(ia.nsegs, std::max<int64_t>(2048, ia.nsegs / 1024));
+            // (the scored segments lead the table.)  The general kernel is several times slower per path: a short
+            // shard gives it an eighth of its segments, not all of them.
+            const int64_t n_warm = std::min<int64_t>(nseg_scored, std::min<int64_t>(std::max<int64_t>(2048, nseg_scored / 1024),
+                                                                                    std::max<int64_t>(256, nseg_scored / 8)));
             IeArgs wa = ia;
             wa.seg_end = n_warm;
-            wa.score_begin = 0;
-            wa.score_end = (uint32_t)n;
             while (wa.waves_per_xcd > 4 && n_warm < (int64_t)8 * wa.waves_per_xcd)
               wa.waves_per_xcd = std::max(4, (wa.waves_per_xcd / 2 / 4) * 4);
             HIP_TRY(c, launch_null_ie(wa, g.method, planes, true, st));
@@ -1141,17 +1173,17 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hipEventRecord(n1, st));
           if (timing) {
             uint64_t tmv[8] = {0};
-            HIP_TRY(c, hipMemcpyAsync(tmv, d_timing, 48, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipMemcpyAsync(tmv, d_timing, 64, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
             const double waves = 8.0 * ia.waves_per_xcd;
-            std::fprintf(stderr, "[ie timing] paths %lld out %d waves %.0f: per-wave Mcycles seg %.2f load %.2f comp(incl load) %.2f lookup %.2f exch %.2f total %.2f\n",
+            std::fprintf(stderr, "[ie timing] paths %lld out %d waves %.0f: per-wave Mcycles seg %.2f load %.2f comp(incl load) %.2f lookup %.2f exch %.2f total %.2f, slowest wave %.2f\n",
                          (long long)n, ia.planes_out != nullptr, waves, tmv[0] / waves / 1e6, tmv[1] / waves / 1e6,
-                         tmv[2] / waves / 1e6, tmv[3] / waves / 1e6, tmv[4] / waves / 1e6, tmv[5] / waves / 1e6);
+                         tmv[2] / waves / 1e6, tmv[3] / waves / 1e6, tmv[4] / waves / 1e6, tmv[5] / waves / 1e6, tmv[6] / 1e6);
           }
           c->ev_null.emplace_back(n0, n1);
-          if (sg.score) {
+          if (scored) {
             c->prof.null_kernel_launches++;
-            c->prof.null_alg_bytes += alg_bytes(cb, n);
+            c->prof.null_alg_bytes += alg_bytes(cb + s0, s1 - s0);
           }
           c->prof.ie_launches++;
           c->prof.ie_overlap_lists += flags[2];
@@ -1160,10 +1192,15 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ran_sparse = true;
         } while (false);
         if (redo) {
-          cb -= chunk_cap;   // same chunk again, now against paths1 itself
+          next = cb;   // same chunk again, now against paths1 itself
           continue;
         }
-        if (!sg.score) continue;
+        if (partial && g.K > 0 && !ran_sparse) {   // priced out of the inclusion-exclusion form: the other kernels score whole chunks
+          split = true;
+          next = cb;
+          continue;
+        }
+        if (!scored) continue;
 
         if (g.K > 0 && use_sparse) do {
           // inspector (once per chunk, shared by all permutation tiles): per joined path the bits paths1 adds
@@ -1197,7 +1234,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           int planes = 5;
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           SparseArgs sp{};
-          if (int rc = sparse_segments(c, u, cb, n, &sp.segs, &sp.nsegs)) return rc;
+          int64_t nseg_scored = 0;
+          if (int rc = sparse_segments(c, u, cb, n, cb, cb + n, &sp.segs, &sp.nsegs, &nseg_scored)) return rc;
           sp.mt = w_mt;
           sp.tot = c->d_tot.p;
           sp.loff0 = jp.p0->d_loff;
@@ -1274,7 +1312,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         // ---- top-k of this chunk ----
         const auto ts0 = std::chrono::steady_clock::now();
         uint32_t nsel = 0;
-        int rc = select_chunk(c, n, c->top_k, &nsel);
+        int rc = select_chunk(c, s0, s1 - s0, c->top_k, &nsel);
         if (rc != GCRE_OK) return rc;
         if (nsel > 0) {
           HIP_TRY(c, c->d_wkey.reserve(nsel));
@@ -1282,8 +1320,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, c->d_wctrls.reserve(nsel));
           HIP_TRY(c, c->d_wrow0.reserve(nsel));
           HIP_TRY(c, c->d_wrow1.reserve(nsel));
-          HIP_TRY(c, launch_gather_winners(c->d_sel.p, nsel, c->d_key.p, c->d_cases.p, c->d_ctrls.p, c->d_row0.p,
-                                           c->d_row1.p, c->d_wkey.p, c->d_wcases.p, c->d_wctrls.p, c->d_wrow0.p,
+          HIP_TRY(c, launch_gather_winners(c->d_sel.p, nsel, c->d_key.p + s0, c->d_cases.p + s0, c->d_ctrls.p + s0,
+                                           c->d_row0.p + s0, c->d_row1.p + s0, c->d_wkey.p, c->d_wcases.p, c->d_wctrls.p, c->d_wrow0.p,
                                            c->d_wrow1.p, st));
           std::vector<uint32_t> h_sel(nsel), h_cases(nsel), h_ctrls(nsel), h_r0(nsel), h_r1(nsel);
           std::vector<uint64_t> h_key(nsel);
@@ -1295,11 +1333,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hipMemcpyAsync(h_r1.data(), c->d_wrow1.p, nsel * 4, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipStreamSynchronize(st));
           for (uint32_t i = 0; i < nsel; i++)
-            cands.push_back(Candidate{key_to_score(h_key[i]), cb + (int64_t)h_sel[i], (int32_t)h_r0[i], (int32_t)h_r1[i],
+            cands.push_back(Candidate{key_to_score(h_key[i]), cb + s0 + (int64_t)h_sel[i], (int32_t)h_r0[i], (int32_t)h_r1[i],
                                       (int32_t)h_cases[i], (int32_t)h_ctrls[i]});
         }
         select_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count();
-        c->prof.paths += n;
+        c->prof.paths += s1 - s0;
       }
     }
     collect_ie_stat();

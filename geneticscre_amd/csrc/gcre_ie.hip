@@ -366,6 +366,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
   int cur_kt = -1;
   u32 valid = 0u;
   u32 lad_base = (a.lad_mode == 0) ? 0u : (u32)(kLadderLevels - 1 + a.lad_mode) * (u32)a.ladder_stride;
+  const u32 lad_keep = (u32)kLadderLevels * (u32)a.ladder_stride;
   bool dirty = false;     // nm holds maxima the global array has not seen
   u32 n_slow = 0u;
 #ifdef GCRE_IE_TIMING
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       const u32 lovv = a.lover[qv];                  // where a long list continues
       const u32 zunit = ((u32)kt * (u32)a.rowsz + (a.rowz[qv] & 0x7fffffffu)) * (u32)a.gz;   // 1 KB units into planesz
       const u32 totv = a.tot[qv];
-      const u32 lhv = a.ladder[lad_base + totv];
+      // segments of another shard's rows: the all-inside row of the ladder (no count is looked up), planes only
+      const u32 lhv = a.ladder[((u64)sidx < (u64)a.score_segs ? lad_base : lad_keep) + totv];
       // the first 8 entries of every list (lists are padded to 8: most lists end there) are wave-uniform: they come
       // through the scalar cache, one s_load_dwordx8 per path, fetched one path ahead of the loads that use them
       typedef u32 __attribute__((ext_vector_type(8))) u32x8;
@@ -712,6 +714,8 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
   tm[5] = __builtin_amdgcn_s_memtime() - tm_begin;
   if (a.timing && lane == 0)
     for (int i = 0; i < 6; i++) atomicAdd((unsigned long long*)a.timing + i, (unsigned long long)tm[i]);
+  if (a.timing && lane == 0) atomicMax((unsigned long long*)a.timing + 6, (unsigned long long)tm[5]);
+  if (a.timing && lane == 0) atomicMax((unsigned long long*)a.timing + 7, (unsigned long long)(__builtin_amdgcn_s_memtime()));
 #endif
   if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
 }
@@ -750,6 +754,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
   // two ladder rows: thresholds ha + hb <= theta (about theta/3 and 2 theta/3), rows are in units of 1/(2 kLadderPerUnit)
   u32 lad_a = (a.lad_mode == 0) ? 0u : (u32)(kLadder2Levels - 1 + a.lad_mode) * (u32)a.ladder_stride;
   u32 lad_b = lad_a;
+  const u32 lad_keep = (u32)kLadder2Levels * (u32)a.ladder_stride;
   bool dirty = false;
   u32 n_slow = 0u;
   __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)a.mt, 0, 0x7fffffff, 0x00020000);
@@ -843,6 +848,7 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
       // ---- per-path metadata of the segment: lane t <-> joined path first + t, both halves ----
       const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
       const u32 rzv = a.rowz[qv];
+      const bool mine = (u64)sidx < (u64)a.score_segs;   // else: rows of another shard, the ladder's all-inside row
       u32 infov[2], lovv[2], zunit[2], totv[2], lha[2], lhb[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
@@ -851,8 +857,8 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
         const u32 hz = (rzv >> 31) ? (u32)(1 - h) : (u32)h;
         zunit[h] = ((u32)kt * (u32)a.rowsz + (rzv & 0x7fffffffu) * 2u + hz) * (u32)a.gz;
         totv[h] = a.tot[(u64)qv * 2 + h];
-        lha[h] = a.ladder[lad_a + totv[h]];
-        lhb[h] = a.ladder[lad_b + totv[h]];
+        lha[h] = a.ladder[(mine ? lad_a : lad_keep) + totv[h]];
+        lhb[h] = a.ladder[(mine ? lad_b : lad_keep) + totv[h]];
       }
       const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 16u);
       u32 B[2][LP];

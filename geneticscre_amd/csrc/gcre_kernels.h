@@ -130,6 +130,7 @@ struct IeArgs {
   int64_t nsegs;
   int64_t seg_begin, seg_end;        // slice of the segment table this launch walks
   uint32_t score_begin, score_end;   // joined paths of the launch outside [begin, end) only produce planes
+  uint32_t score_segs;               // the same range in segments: the table's first score_segs segments (they do not straddle)
   int nkt, waves_per_xcd, K;
   int g0, gz, go;            // plane groups (4 planes each) of the three plane arrays
   int lad_mode;              // method-1 kernel: 0 thresholds from the running maxima, 1 look nothing up, 2 look everything up
@@ -214,6 +215,18 @@ hipError_t launch_range_union(const uint64_t* p1, const uint64_t* pz, const int3
 // ---- top-k selection over key[0..count) ----
 hipError_t launch_hist(const uint64_t* key, int64_t count, int shift, uint64_t prefix, uint32_t* hist256,
                        hipStream_t stream);
+// all eight digit passes queued back to back, the state between them stays on the device: afterwards st->prefix is the
+// need-th largest key, st->greater the number of keys in higher buckets, st->need / st->eq_count the wanted / present
+// number of keys equal to it
+struct SelectState {
+  uint64_t prefix;
+  int64_t need;
+  int64_t greater;
+  uint32_t eq_count;
+  uint32_t pad;
+};
+hipError_t launch_radix_select(const uint64_t* key, int64_t count, int64_t need, uint32_t* hist256, SelectState* st,
+                               hipStream_t stream);
 // appends every i with key[i] > thr (any order) to out[], counter in *n_out
 hipError_t launch_collect_gt(const uint64_t* key, int64_t count, uint64_t thr, uint32_t* out, uint32_t* n_out,
                              uint32_t cap, hipStream_t stream);

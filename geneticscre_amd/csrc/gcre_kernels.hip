@@ -621,6 +621,57 @@ hipError_t launch_hist(const uint64_t* key, int64_t count, int shift, uint64_t p
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_select_init(SelectState* st, i64 need, u32* hist256) {
+  hist256[threadIdx.x] = 0;
+  if (threadIdx.x == 0) *st = SelectState{0, need, 0, 0, 0};
+}
+
+__global__ __launch_bounds__(256) void k_hist_st(const u64* key, i64 count, int shift, const SelectState* st, u32* hist256) {
+  __shared__ u32 h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 prefix = st->prefix;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (i64)gridDim.x * blockDim.x) {
+    const u64 k = key[i];
+    const bool match = (shift == 56) ? true : ((k >> (shift + 8)) == prefix);
+    if (match) atomicAdd(&h[(u32)(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist256[threadIdx.x], h[threadIdx.x]);
+}
+
+// the bucket that holds the need-th largest key of this digit; leaves the histogram zeroed for the next pass
+__global__ __launch_bounds__(256) void k_select_step(SelectState* st, u32* hist256) {
+  __shared__ u32 h[256];
+  h[threadIdx.x] = hist256[threadIdx.x];
+  hist256[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  SelectState s = *st;
+  i64 cum = 0;
+  int b = 255;
+  for (; b > 0; b--) {
+    if (cum + h[b] >= s.need) break;
+    cum += h[b];
+  }
+  s.greater += cum;
+  s.need -= cum;
+  s.eq_count = h[b];
+  s.prefix = (s.prefix << 8) | (u64)b;
+  *st = s;
+}
+
+hipError_t launch_radix_select(const uint64_t* key, int64_t count, int64_t need, uint32_t* hist256, SelectState* st,
+                               hipStream_t stream) {
+  const int grid = (int)hmin((count + 2047) / 2048, 2048);
+  hipLaunchKernelGGL(k_select_init, dim3(1), dim3(256), 0, stream, st, need, hist256);
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    hipLaunchKernelGGL(k_hist_st, dim3(grid > 0 ? grid : 1), dim3(256), 0, stream, key, count, shift, st, hist256);
+    hipLaunchKernelGGL(k_select_step, dim3(1), dim3(256), 0, stream, st, hist256);
+  }
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_collect_gt(const u64* key, i64 count, u64 thr, u32* out, u32* n_out, u32 cap) {
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (i64)gridDim.x * blockDim.x) {
     if (key[i] > thr) {

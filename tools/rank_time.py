@@ -7,11 +7,16 @@ import numpy as np
 import bench
 from geneticscre_amd import api
 
-cfg = bench.CONFIGS["roofline"]
-prob, masks = bench.build_inputs(cfg, 20261003, 100)
-plan = api.ResidentPlan(prob, packed_masks=masks)
+WEAK = os.environ.get("WEAK") == "1"      # weak scaling: 10,000 permutations per rank instead of 10,000 in total
+plan = None
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     times = []
+    if plan is None or WEAK:
+        cfg = dict(bench.CONFIGS["roofline"])
+        if WEAK:
+            cfg["perms"] *= world
+        prob, masks = bench.build_inputs(cfg, 20261003, 100)
+        plan = api.ResidentPlan(prob, packed_masks=masks, mask_seed=None if masks is not None else 1)
     for rank in sorted({0, world // 2, world - 1}):
         plan.run(rank, world)
         t0 = time.perf_counter()
