@@ -108,6 +108,8 @@ struct gcre_ctx {
   double* d_dmax = nullptr;          // method 2 null table (vtmax)
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
+  int ie_batch = 2;                  // segments per ticket (GCRE_IE_BATCH)
+  uint32_t* d_queue = nullptr;       // ticket counters of the pruned kernels' work queues (8 x 16 words)
   uint32_t* d_max_tot = nullptr;     // 8 words: largest carrier total of the chunk, "reduced operand is wrong", overlap lists,
                                      // looked-up tiles, entries reserved in the long-list area
   uint32_t* d_ladder = nullptr;      // method 1: pruning ladder of the null table [kLadderLevels][TD]
@@ -1169,7 +1171,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             HIP_TRY(c, launch_null_ie(wa, g.method, planes, true, st));
             ia.seg_begin = n_warm;
           }
-          if (ia.seg_begin < ia.seg_end) HIP_TRY(c, launch_null_ie(ia, g.method, planes, c->d_ladder == nullptr, st));
+          if (ia.seg_begin < ia.seg_end) {
+            ia.queue = c->d_queue;
+            ia.batch = c->ie_batch;
+            HIP_TRY(c, hipMemsetAsync(ia.queue, 0, 8 * 16 * 4, st));
+            HIP_TRY(c, launch_null_ie(ia, g.method, planes, c->d_ladder == nullptr, st));
+          }
           HIP_TRY(c, hipEventRecord(n1, st));
           if (timing) {
             uint64_t tmv[8] = {0};
@@ -1469,12 +1476,14 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   if (const char* e = std::getenv("GCRE_NULL_KERNEL"))
     c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : !std::strcmp(e, "ie") ? 3 : 0;
   if (const char* e = std::getenv("GCRE_IE_PRUNE")) c->ie_prune = std::atoi(e) != 0;
+  if (const char* e = std::getenv("GCRE_IE_BATCH")) c->ie_batch = std::min(std::max(std::atoi(e), 1), 4096);
   if (const char* e = std::getenv("GCRE_PLANES_OUT_MAX_MB")) c->planes_out_max = (size_t)std::max(0ll, std::atoll(e)) << 20;
   if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));
 
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_case_mask, (size_t)g.Wp * 8) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_max_tot, 32) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_queue, 8 * 16 * 4) == hipSuccess;
   if (ok && g.Kpad > 0) {
     ok = hipMalloc((void**)&c->d_masks, (size_t)2 * g.Wp * g.Kpad * 4) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_null, (size_t)g.Kpad * 4) == hipSuccess;
@@ -1499,7 +1508,7 @@ void gcre_destroy(gcre_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void* p : {(void*)c->d_case_mask, (void*)c->d_masks, (void*)c->d_t32, (void*)c->d_dvt, (void*)c->d_dmax,
-                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot, (void*)c->d_ladder})
+                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot, (void*)c->d_queue, (void*)c->d_ladder})
     if (p) (void)hipFree(p);
   for (auto* b : {&c->d_row0, &c->d_row1, &c->d_tot, &c->d_cases, &c->d_ctrls, &c->d_sel, &c->d_small, &c->d_chunk,
                   &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})

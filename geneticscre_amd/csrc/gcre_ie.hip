@@ -28,6 +28,7 @@
 namespace gcre {
 
 constexpr int kIeWaves = 4;
+constexpr int kIeQueueStride = 16;  // words between two ticket counters (64 B)
 constexpr int kIeRefresh = 32;      // segments between two reads of the global maxima once the thresholds have settled
 
 __device__ __forceinline__ u32 maj3(u32 a, u32 b, u32 c) { return (a & b) | ((a ^ b) & c); }
@@ -42,6 +43,72 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
 }
 
 __device__ __forceinline__ u32 rdlane(u32 v, u32 t) { return (u32)__builtin_amdgcn_readlane((int)v, (int)t); }
+
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u32 t = (u32)__shfl_xor((int)v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// The work queues of the pruned kernels: the segment table of a launch (sorted by the added rows) is cut into
+// eight contiguous parts, one per XCD; each part's batches of a.batch segments are handed out tile-major by its own
+// ticket counter (zeroed by the host before the launch).  The waves of an XCD therefore work on a few hundred
+// neighbouring segments at any time -- a handful of pivot genes, whose count planes and mask rows stay in its L2.
+// (Measured: larger batches or one queue per CU widen that window past the L2 and cost 5-15 %; one queue for the
+// whole chip mixes all eight windows in every L2 and costs 8 %.)  A wave whose queue is empty takes tickets from
+// the queue with the most work left.
+struct WorkQueue {
+  // Everything the queue needs between two tickets lives in LDS (8 words per wave), read back where it is used: the
+  // kernels have no scalar registers to spare across a segment.
+  // [0] current queue  [1] its first batch  [2] its batch count  [3] batches per tile  [4] queues  [5] tiles  [6,7] counters
+  volatile u32* st;
+  __device__ __forceinline__ u32 get(int i) const { return (u32)__builtin_amdgcn_readfirstlane(st[i]); }
+  __device__ __forceinline__ u32* counters() const { return (u32*)(((u64)get(7) << 32) | (u64)get(6)); }
+  __device__ __forceinline__ void init(u32* counters, u32 nbatch, u32 nq, u32 nkt) {
+    st[3] = nbatch;
+    st[4] = nq;
+    st[5] = nkt;
+    st[6] = (u32)(u64)counters;
+    st[7] = (u32)((u64)counters >> 32);
+  }
+  __device__ __forceinline__ u32 first_of(u32 j, u32 nbatch, u32 nq) const { return (u32)((u64)nbatch * j / nq); }
+  __device__ __forceinline__ void select(u32 j) {
+    const u32 nbatch = get(3), nq = get(4);
+    const u32 lo = first_of(j, nbatch, nq);
+    st[0] = j;
+    st[1] = lo;
+    st[2] = first_of(j + 1, nbatch, nq) - lo;
+  }
+  __device__ __forceinline__ u32 take(int lane) const {
+    u32 t = 0u;
+    if (lane == 0) t = atomicAdd(counters() + get(0) * kIeQueueStride, 1u);
+    return t;
+  }
+  // the queue with the most tickets left (read past the caches), false when every queue is empty
+  __device__ __forceinline__ bool steal(int lane) {
+    const u32 nbatch = get(3), nq = get(4), nkt = get(5);
+    u32* cnt = counters();
+    u32 best = 0u, bq = 0u;
+    for (u32 j = (u32)lane; j < nq; j += 64u) {
+      const u32 taken = __hip_atomic_load(cnt + j * kIeQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 all = (first_of(j + 1, nbatch, nq) - first_of(j, nbatch, nq)) * nkt;
+      const u32 left = taken < all ? all - taken : 0u;
+      if (left > best) {
+        best = left;
+        bq = j;
+      }
+    }
+    const u32 m = __builtin_amdgcn_readfirstlane(wave_max_u32(best));
+    if (m == 0u) return false;
+    const u64 who = __ballot(best == m);
+    select(rdlane(bq, (u32)(__ffsll((long long)who) - 1)));
+    return true;
+  }
+};
+
 
 // The general kernel: both methods, every count looked up (no pruning).  Runs the signed method, and for method 1 the
 // warm-up slice that seeds the pruned kernel's thresholds.  L = counter planes of the joined paths, a multiple of 4.
@@ -353,10 +420,6 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
   __shared__ u32 nmax_lds[kIeWaves][32 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int xcd = blockIdx.x & 7;
-  const i64 wi = (i64)(blockIdx.x >> 3) * kIeWaves + wave;
-  const i64 wx = a.waves_per_xcd;
-  const i64 slices = 8 * wx;
   const u32 lane4 = (u32)lane * 4u;
   u32* nm = nmax_lds[wave] + lane;
 #pragma unroll
@@ -421,11 +484,30 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
     dirty = false;
   };
 
-  for (int step = 0; step < a.nkt; step++) {
-    const i64 item = (i64)xcd * a.nkt * wx + wi + (i64)step * wx;
-    const int kt = (int)(item / slices);
-    const i64 sl = item % slices;
-    if (a.seg_begin + sl >= a.seg_end) continue;   // nothing for this wave in this tile
+  // Work queues (WorkQueue above): segments differ in length and tiles in how many counts they look up -- a fixed
+  // split of the table leaves the slowest wave 10-40 % behind the average.
+  __shared__ u32 wq_state[kIeWaves][8];
+  WorkQueue wq;
+  wq.st = wq_state[wave];
+  wq.init(a.queue, (u32)((a.seg_end - a.seg_begin + a.batch - 1) / a.batch), 8u, (u32)a.nkt);
+  {
+    wq.select(blockIdx.x & 7u);   // workgroups are dealt round the XCDs: blocks b and b + 8 share an L2
+  }
+  u32 ticket = wq.take(lane);
+  int since = 0, period = 1;   // thresholds: refresh after 1, 2, 4, .. segments while they climb, then every kIeRefresh
+  for (;;) {
+    const u32 work = __builtin_amdgcn_readfirstlane(ticket);
+    const u32 q_n = wq.get(2);
+    if (work >= q_n * wq.get(5)) {
+      // this queue is empty: take from the fullest one; every wave ends once it has seen them all empty
+      if (!wq.steal(lane)) break;
+      ticket = wq.take(lane);
+      continue;
+    }
+    ticket = wq.take(lane);   // the next ticket is on its way while this batch is worked on
+    const int kt = (int)(work / q_n);
+    const i64 s_lo = a.seg_begin + (i64)(wq.get(1) + (work - (u32)kt * q_n)) * a.batch;
+    const i64 s_hi = s_lo + a.batch < a.seg_end ? s_lo + a.batch : a.seg_end;
     if (kt != cur_kt) {
       flush_tile();
       cur_kt = kt;
@@ -433,9 +515,10 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       const int live = a.K - kt * 2048 - lane * 32;
       valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
       if (a.lad_mode == 0) lad_base = 0u;
+      since = 0;
+      period = 1;
     }
-    int since = 0, period = 1;   // thresholds: refresh after 1, 2, 4, .. segments while they climb, then every kIeRefresh
-    for (i64 sidx = a.seg_begin + sl; sidx < a.seg_end; sidx += slices) {
+    for (i64 sidx = s_lo; sidx < s_hi; sidx++) {
       const u32 row0 = segs[sidx].row0;
       const u32 first = segs[sidx].first;
       const u32 npaths = segs[sidx].n;
@@ -739,10 +822,6 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
   __shared__ u32 nmax_lds[kIeWaves][32 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int xcd = blockIdx.x & 7;
-  const i64 wi = (i64)(blockIdx.x >> 3) * kIeWaves + wave;
-  const i64 wx = a.waves_per_xcd;
-  const i64 slices = 8 * wx;
   const u32 lane4 = (u32)lane * 4u;
   u32* nm = nmax_lds[wave] + lane;
 #pragma unroll
@@ -822,11 +901,29 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
     return blo | bhi;
   };
 
-  for (int step = 0; step < a.nkt; step++) {
-    const i64 item = (i64)xcd * a.nkt * wx + wi + (i64)step * wx;
-    const int kt = (int)(item / slices);
-    const i64 sl = item % slices;
-    if (a.seg_begin + sl >= a.seg_end) continue;
+  // work queues as in k_null_ie_m1
+  __shared__ u32 wq_state[kIeWaves][8];
+  WorkQueue wq;
+  wq.st = wq_state[wave];
+  wq.init(a.queue, (u32)((a.seg_end - a.seg_begin + a.batch - 1) / a.batch), 8u, (u32)a.nkt);
+  {
+    wq.select(blockIdx.x & 7u);   // workgroups are dealt round the XCDs: blocks b and b + 8 share an L2
+  }
+  u32 ticket = wq.take(lane);
+  int since = 0, period = 1;
+  for (;;) {
+    const u32 work = __builtin_amdgcn_readfirstlane(ticket);
+    const u32 q_n = wq.get(2);
+    if (work >= q_n * wq.get(5)) {
+      // this queue is empty: take from the fullest one; every wave ends once it has seen them all empty
+      if (!wq.steal(lane)) break;
+      ticket = wq.take(lane);
+      continue;
+    }
+    ticket = wq.take(lane);   // the next ticket is on its way while this batch is worked on
+    const int kt = (int)(work / q_n);
+    const i64 s_lo = a.seg_begin + (i64)(wq.get(1) + (work - (u32)kt * q_n)) * a.batch;
+    const i64 s_hi = s_lo + a.batch < a.seg_end ? s_lo + a.batch : a.seg_end;
     if (kt != cur_kt) {
       flush_tile();
       cur_kt = kt;
@@ -834,9 +931,10 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
       const int live = a.K - kt * 2048 - lane * 32;
       valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
       if (a.lad_mode == 0) lad_a = lad_b = 0u;
+      since = 0;
+      period = 1;
     }
-    int since = 0, period = 1;
-    for (i64 sidx = a.seg_begin + sl; sidx < a.seg_end; sidx += slices) {
+    for (i64 sidx = s_lo; sidx < s_hi; sidx++) {
       const u32 row0 = segs[sidx].row0;
       const u32 first = segs[sidx].first;
       const u32 npaths = segs[sidx].n;
