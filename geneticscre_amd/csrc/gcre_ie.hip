@@ -798,7 +798,6 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
   if (a.timing && lane == 0)
     for (int i = 0; i < 6; i++) atomicAdd((unsigned long long*)a.timing + i, (unsigned long long)tm[i]);
   if (a.timing && lane == 0) atomicMax((unsigned long long*)a.timing + 6, (unsigned long long)tm[5]);
-  if (a.timing && lane == 0) atomicMax((unsigned long long*)a.timing + 7, (unsigned long long)(__builtin_amdgcn_s_memtime()));
 #endif
   if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
 }
@@ -1401,15 +1400,22 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
   constexpr u32 kOverChunk = 2048;   // entries of the overflow area a wave reserves at a time
   u32 chunk_at = 0u, chunk_left = 0u;
   // the row numbers of the next group of four paths (two dependent loads) are fetched while this one is worked on
+  // (rng: the uid's row of the excess table, or kNoRange when an earlier path of this launch shares the uid -- the
+  // check "excess inside paths0[idx]" is per uid, one path of it is enough)
+  constexpr u32 kNoRange = 0xffffffffu;
   auto fetch = [&](i64 base, u32& r0, u32& r1raw, u32& zraw, u32& rng) {
     const i64 i = (base + (lane >> 4) < a.count) ? base + (lane >> 4) : a.count - 1;
     r0 = a.row0[i];
     r1raw = a.row1[i];
     zraw = a.zindex ? (u32)a.zindex[r1raw & 0x7fffffffu] : (r1raw & 0x7fffffffu);
-    rng = a.excess ? (u32)a.range_of[r0] : 0u;
+    rng = kNoRange;
+    if (a.excess && (i == 0 || a.row0[i - 1] != r0)) rng = (u32)a.range_of[r0];
   };
   u32 n_r0 = 0, n_r1raw = 0, n_zraw = 0, n_rng = 0;
   if (wave * 4 < a.count) fetch(wave * 4, n_r0, n_r1raw, n_zraw, n_rng);
+  u64 cmw[NW];   // this lane's words of the case mask: the same for every path
+#pragma unroll
+  for (int it = 0; it < NW; it++) cmw[it] = (NIT > 0 && it * 16 + sl < Wp) ? a.case_mask[it * 16 + sl] : 0;
   for (i64 base = wave * 4; base < a.count; base += nwaves * 4) {
     const bool active = base + (lane >> 4) < a.count;
     const i64 i = active ? base + (lane >> 4) : a.count - 1;   // idle rows shadow the last path and write nothing
@@ -1423,7 +1429,7 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
     // without a hint z IS paths1[loc]; with one, paths1[loc] = z | excess (k_range_union checked z inside it) and
     // the union U of the excess over every row this uid joins must lie inside paths0[idx] -- checked below -- so
     // paths0[idx] | paths1[loc] == paths0[idx] | z for every path of the uid.
-    const u64* uu = a.excess ? a.excess + (size_t)rng * a.S : nullptr;
+    const u64* uu = (rng != kNoRange) ? a.excess + (size_t)rng * a.S : nullptr;
     u64* out = (a.res && active) ? a.res + (size_t)(a.first + i) * a.S : nullptr;
     const bool swap = (M == 2) && (r1raw >> 31) != 0;
     const u64* uh[2] = {(uu && swap) ? uu + Wp : uu, (uu && !swap) ? uu + Wp : uu};
@@ -1442,12 +1448,11 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
       dv[h] += (u32)__popcll(zk & ~xk) | ((u32)__popcll(zk & xk) << 16);
     };
     if constexpr (NIT > 0) {
-      u64 uw[M][NW], cmw[NW];
+      u64 uw[M][NW];
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
         const int k = it * 16 + sl;
         const bool in = k < Wp;
-        cmw[it] = in ? a.case_mask[k] : 0;
 #pragma unroll
         for (int h = 0; h < M; h++) {
           xw[h][it] = in ? x[h * Wp + k] : 0;
@@ -1485,18 +1490,17 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
         my_max_tot = max(my_max_tot, tot[h]);
       }
     }
+    double score = 0.0;   // looked up here, stored after the lists are out: the wave does not sit on the (cold) table load
     if (active && sl == 0) {
       if constexpr (M == 1) {
-        const double s = a.dvt[(size_t)sp_diag_offset(tot[0]) + inc[0]];   // vt[cases][ctrls], methods.h:90
-        a.key[i] = ie_score_key(s);
+        score = a.dvt[(size_t)sp_diag_offset(tot[0]) + inc[0]];   // vt[cases][ctrls], methods.h:90
         a.tot[i] = tot[0];
         a.cases[i] = inc[0];
         a.ctrls[i] = inm[0];
       } else {
         // (+) half: case_pos = inc[0], ctrl_neg = inm[0]; (-) half: ctrl_pos = inc[1], case_neg = inm[1] (methods.h:182-185)
         const u32 case_pos = inc[0], ctrl_neg = inm[0], ctrl_pos = inc[M - 1], case_neg = inm[M - 1];
-        const double s = a.dvt[(size_t)sp_diag_offset(tot[0]) + case_pos] + a.dvt[(size_t)sp_diag_offset(tot[M - 1]) + case_neg];
-        a.key[i] = ie_score_key(s);
+        score = a.dvt[(size_t)sp_diag_offset(tot[0]) + case_pos] + a.dvt[(size_t)sp_diag_offset(tot[M - 1]) + case_neg];
         a.tot[2 * i] = tot[0];
         a.tot[2 * i + 1] = tot[M - 1];
         a.cases[i] = case_pos + case_neg;        // methods.h:256-257
@@ -1580,6 +1584,7 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
         a.lover[d] = ovb;
       }
     }
+    if (active && sl == 0) a.key[i] = ie_score_key(score);
   }
   if (my_max_tot) atomicMax(a.max_tot, my_max_tot);
   if (my_bad) *a.bad = 1u;
