@@ -384,16 +384,17 @@ class JoinExec:
 
     def join(self, uids, paths0: PathSet, paths1: PathSet, paths_res: Optional[PathSet] = None,
              shard: Optional[Tuple[int, int]] = None, d_null_out: int = 0,
-             keep: Optional[Tuple[int, int]] = None) -> JoinResult:
+             keep: Optional[Tuple[int, int]] = None, keep_mode: int = 1) -> JoinResult:
         """JoinExec::join (src/join_base.cpp:189-264).  ``paths_res`` receives the joined rows when given.
         ``uids`` is a UidRelSet (uploaded for this call) or a DeviceUids (already resident).  ``shard`` restricts
         scoring to a range of joined paths; ``keep`` restricts the rows written to ``paths_res`` to a range (plus
-        the scored shard) -- the rows this device's shards of the later joins will read."""
+        the scored shard) -- the rows this device's shards of the later joins will read -- or, with ``keep_mode`` 2,
+        only the rows that get count planes (all rows are still written)."""
         opts = gcre_join_opts(0, 0, 0, 0, None, 0, 0)
         if shard is not None:
             opts.sharded, opts.shard_begin, opts.shard_end = 1, int(shard[0]), int(shard[1])
         if keep is not None:
-            opts.keep_ranged, opts.keep_begin, opts.keep_end = 1, int(keep[0]), int(keep[1])
+            opts.keep_ranged, opts.keep_begin, opts.keep_end = int(keep_mode), int(keep[0]), int(keep[1])
         if d_null_out:
             opts.d_null_out = ctypes.c_void_p(int(d_null_out))
         res = gcre_result()
@@ -533,7 +534,8 @@ class ResidentPlan:
     def __init__(self, problem, device: int = 0, packed_masks: Optional[np.ndarray] = None,
                  mask_seed: Optional[int] = None):
         self.problem = problem
-        self._needed: Dict[tuple, Tuple[int, int]] = {}
+        self._needed: Dict[tuple, Optional[Tuple[int, int]]] = {}
+        self._first: Dict[str, np.ndarray] = {}
         self._window: Optional[int] = None
         ex = self.ex = JoinExec(problem.method, problem.n_cases, problem.n_ctrls, problem.iterations, device)
         ex.top_k = problem.top_k
@@ -591,30 +593,44 @@ class ResidentPlan:
             "5": (k.get("3"), k.get("3"), None),
         }[name]
 
+    def _uids_of(self, name: str, b: int, e: int) -> Tuple[int, int]:
+        """Rows of paths0 (uids) that own the joined paths [b, e) of level ``name``."""
+        if e <= b:
+            return (0, 0)
+        if name not in self._first:
+            u = self.problem.levels.uids[name]
+            self._first[name] = np.concatenate([[0], np.cumsum(np.maximum(np.asarray(u.count, dtype=np.int64), 0))])
+        first = self._first[name]
+        return (int(np.searchsorted(first, b, side="right")) - 1, int(np.searchsorted(first, e - 1, side="right")))
+
     def needed_rows(self, name: str, rank: int, world: int) -> Optional[Tuple[int, int]]:
-        """Rows of the set level ``name`` keeps that THIS rank's shards of the later levels read as paths0: level 3's
-        rows are only read through the uids of the level-4 / level-5 shards.  Levels 1 and 2 are small and are also
-        read as paths1 / reduced operands: kept whole."""
-        if world == 1 or name != "3" or "5" in self.uids:   # level 5 reads every row of level 3 as its paths1
+        """What THIS rank needs of the set level ``name`` keeps, as a range of its rows (None: everything).
+        Level 3's rows are only read as paths0 of the level-4 shard: the others are not produced at all
+        (gcre_join_opts.keep_ranged = 1).  Levels 1 and 2 are also read as paths1 / reduced operands, so all their
+        rows are written, but count planes are only needed for the rows this rank's work on the next level reads
+        as paths0 (keep_ranged = 2, see ``keep_mode``).  With level 5 in the run every rank needs all of levels 2
+        and 3 (level 5 joins level 3 with itself through level 2's planes)."""
+        if world == 1 or "5" in self.uids or name not in ("1a", "2", "3"):
             return None
         key = (name, rank, world)
         if key in self._needed:
             return self._needed[key]
-        lo, hi = None, None
-        for later in ("4",):
-            if later not in self.uids:
-                continue
-            b, e = self.shard(later, rank, world)
-            if e <= b:
-                continue
-            u = self.problem.levels.uids[later]
-            first = np.concatenate([[0], np.cumsum(np.maximum(np.asarray(u.count, dtype=np.int64), 0))])
-            i0 = int(np.searchsorted(first, b, side="right")) - 1          # uid that owns joined path b
-            i1 = int(np.searchsorted(first, e - 1, side="right")) - 1      # uid that owns joined path e-1
-            lo = i0 if lo is None else min(lo, i0)
-            hi = i1 + 1 if hi is None else max(hi, i1 + 1)
-        self._needed[key] = (0, 0) if lo is None else (lo, hi)
+        nxt = {"1a": "2", "2": "3", "3": "4"}[name]
+        if nxt not in self.uids:
+            self._needed[key] = None if name != "3" else (0, 0)
+            return self._needed[key]
+        # joined paths of the next level this rank works on: its shard, and whatever the level after needs of it
+        b, e = self.shard(nxt, rank, world)
+        more = self.needed_rows(nxt, rank, world) if nxt in ("2", "3") else (0, 0)
+        if more is None:
+            more = (0, self.uids[nxt].total_paths)
+        if more[1] > more[0]:
+            b, e = (min(b, more[0]), max(e, more[1])) if e > b else more
+        self._needed[key] = self._uids_of(nxt, b, e)
         return self._needed[key]
+
+    def keep_mode(self, name: str) -> int:
+        return 1 if name == "3" else 2
 
     def shard(self, name: str, rank: int, world: int) -> Tuple[int, int]:
         total = self.uids[name].total_paths
@@ -643,7 +659,7 @@ class ResidentPlan:
                 b, e = self.shard(name, rank, world)
                 r = self.ex.join(self.uids[name], p0, p1, res, shard=(b, e) if world > 1 else None,
                                  d_null_out=(d_null_out + 4 * k0) if d_null_out else 0,
-                                 keep=self.needed_rows(name, rank, world))
+                                 keep=self.needed_rows(name, rank, world), keep_mode=self.keep_mode(name))
                 for k, v in self.ex.profile().items():
                     prof[k] = prof.get(k, 0) + v
                 if on_level is not None:

@@ -108,6 +108,7 @@ struct gcre_ctx {
   double* d_dmax = nullptr;          // method 2 null table (vtmax)
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
+  int ie_warm_segs = 2048;           // least number of segments in the warm-up slice (GCRE_IE_WARM)
   int ie_batch = 2;                  // segments per ticket (GCRE_IE_BATCH)
   uint32_t* d_queue = nullptr;       // ticket counters of the pruned kernels' work queues (8 x 16 words)
   uint32_t* d_max_tot = nullptr;     // 8 words: largest carrier total of the chunk, "reduced operand is wrong", overlap lists,
@@ -175,6 +176,7 @@ struct gcre_pathset {
   mutable size_t planes_bytes = 0;   // capacity of d_planes
   mutable uint64_t planes_epoch = 0;
   mutable bool planes_valid = false;
+  mutable int64_t planes_lo = 0, planes_hi = 0;   // rows whose planes are valid (a multi-device join fills a range)
 };
 
 // UidRelSet (src/gcre.h:49-90) resident on the device: prefix sums of count, locations, signs
@@ -191,7 +193,7 @@ struct gcre_uids {
   int32_t* d_signs;
   std::vector<int64_t> h_path_idx;   // host copy, for building the sparse kernel's segment tables
   std::vector<int64_t> h_location;   // host copy: segments are ordered by the paths1 rows they join (L2 reuse of their planes)
-  struct SegCache { int64_t first, count, score_b, score_e; int64_t nsegs, nscored; SparseSeg* d_segs; };
+  struct SegCache { int64_t first, count, score_b, score_e, plane_b, plane_e; int64_t nsegs, nscored; SparseSeg* d_segs; };
   mutable std::vector<SegCache> seg_cache;
   // optional hint (gcre_uids_set_reduced): paths0[idx] | paths1[loc] == paths0[idx] | red[red_index[loc]] for every
   // joined path; checked on the device for every join, ignored when it does not hold
@@ -395,9 +397,11 @@ int plane_groups_for(uint32_t max_count) {
   return std::max(2, (bits + 3) / 4);
 }
 
-bool planes_current(const gcre_ctx* c, const gcre_pathset* ps) {
-  return ps->d_planes && ps->planes_valid && ps->planes_epoch == c->mask_epoch;
+// planes of rows [lo, hi) are there for the current masks
+bool planes_cover(const gcre_ctx* c, const gcre_pathset* ps, int64_t lo, int64_t hi) {
+  return ps->d_planes && ps->planes_valid && ps->planes_epoch == c->mask_epoch && (hi <= lo || (ps->planes_lo <= lo && hi <= ps->planes_hi));
 }
+bool planes_current(const gcre_ctx* c, const gcre_pathset* ps) { return planes_cover(c, ps, 0, ps->nrows); }
 
 size_t plane_bytes(const gcre_ctx* c, int64_t nrows, int groups) {
   const size_t nkt = (size_t)((c->win_K + kSparseTile - 1) / kSparseTile);
@@ -472,16 +476,22 @@ int ensure_planes(gcre_ctx* c, const gcre_pathset* ps) {
                                  groups, ps->d_planes, c->stream));
   ps->planes_epoch = c->mask_epoch;
   ps->planes_valid = true;
+  ps->planes_lo = 0;
+  ps->planes_hi = ps->nrows;
   return GCRE_OK;
 }
 
 // Segment table of the joined paths [first, first+count): runs of paths that share their paths0 row, at most
 // kSparseSegMax long, none straddling the scored range [score_b, score_e).  The scored segments come first
-// (*nscored of them).  Cached per uids object (the join index is resident input; repeated joins reuse it).
+// (*nscored of them); of the others only the paths inside [plane_b, plane_e) are listed (the rest need no count
+// planes).  Cached per uids object (the join index is resident input; repeated joins reuse it).
 int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t count, int64_t score_b, int64_t score_e,
-                    const SparseSeg** d_out, int64_t* nsegs, int64_t* nscored) {
+                    int64_t plane_b, int64_t plane_e, const SparseSeg** d_out, int64_t* nsegs, int64_t* nscored) {
+  plane_b = std::max(plane_b, first);
+  plane_e = std::min(plane_e, first + count);
   for (const auto& sc : u.seg_cache)
-    if (sc.first == first && sc.count == count && sc.score_b == score_b && sc.score_e == score_e) {
+    if (sc.first == first && sc.count == count && sc.score_b == score_b && sc.score_e == score_e && sc.plane_b == plane_b &&
+        sc.plane_e == plane_e) {
       *d_out = sc.d_segs;
       *nsegs = sc.nsegs;
       *nscored = sc.nscored;
@@ -499,8 +509,13 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
     const int64_t cut[4] = {lo, std::min(std::max(score_b, lo), hi), std::min(std::max(score_e, lo), hi), hi};
     for (int part = 0; part < 3; part++) {
       std::vector<SparseSeg>& dst = (part == 1) ? segs : rest;
-      for (int64_t a = cut[part]; a < cut[part + 1]; a += kSparseSegMax)
-        dst.push_back(SparseSeg{(uint32_t)i, (uint32_t)(a - first), (uint32_t)std::min<int64_t>(kSparseSegMax, cut[part + 1] - a)});
+      int64_t a0 = cut[part], a1 = cut[part + 1];
+      if (part != 1) {   // planes only: clip to the rows that want them
+        a0 = std::max(a0, plane_b);
+        a1 = std::min(a1, plane_e);
+      }
+      for (int64_t a = a0; a < a1; a += kSparseSegMax)
+        dst.push_back(SparseSeg{(uint32_t)i, (uint32_t)(a - first), (uint32_t)std::min<int64_t>(kSparseSegMax, a1 - a)});
     }
   }
   const size_t n_scored = segs.size();
@@ -537,7 +552,7 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
     (void)hipFree(u.seg_cache.front().d_segs);
     u.seg_cache.erase(u.seg_cache.begin());
   }
-  u.seg_cache.push_back({first, count, score_b, score_e, (int64_t)segs.size(), (int64_t)n_scored, d});
+  u.seg_cache.push_back({first, count, score_b, score_e, plane_b, plane_e, (int64_t)segs.size(), (int64_t)n_scored, d});
   *d_out = d;
   *nsegs = (int64_t)segs.size();
   *nscored = (int64_t)n_scored;
@@ -606,7 +621,8 @@ struct JoinPlan {
   bool sharded;
   int64_t shard_begin, shard_end;
   void* d_null_out;
-  bool keep_ranged = false;
+  bool keep_ranged = false;        // rows outside [keep_begin, keep_end) and the shard are not produced at all
+  bool planes_ranged = false;      // every row is produced, count planes only for [keep_begin, keep_end) and the shard
   int64_t keep_begin = 0, keep_end = 0;
 };
 
@@ -778,6 +794,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   c->prof = gcre_profile{};
   double select_ms = 0;
   bool keep_planes_done = false;
+  int64_t keep_planes_lo = 0, keep_planes_hi = 0;
   uint32_t keep_max_tot = 0;
 
   if (P > 0) {
@@ -791,6 +808,18 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     if (jp.keep_ranged) {
       kb = std::max<int64_t>(0, std::min(jp.keep_begin, P));
       ke = std::max(kb, std::min(jp.keep_end, P));
+    }
+    // rows of `res` that get count planes: every produced row, or (gcre_join_opts.keep_ranged == 2) the hull of
+    // [keep_begin, keep_end) and the shard
+    int64_t pl_b = std::min(kb, se > sb ? sb : kb), pl_e = std::max(ke, se > sb ? se : ke);
+    if (jp.planes_ranged) {
+      const int64_t qb = std::max<int64_t>(0, std::min(jp.keep_begin, P)), qe = std::max(qb, std::min(jp.keep_end, P));
+      pl_b = qe > qb ? qb : (se > sb ? sb : 0);
+      pl_e = qe > qb ? qe : (se > sb ? se : 0);
+      if (se > sb) {
+        pl_b = std::min(pl_b, sb);
+        pl_e = std::max(pl_e, se);
+      }
     }
     if (!keep || kb >= ke) {
       if (se > sb) segs.push_back({sb, se, sb, se});
@@ -862,18 +891,42 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       return GCRE_OK;
     };
     const auto tp0 = std::chrono::steady_clock::now();
+    // rows of paths0 this call reads: the uids of the joined paths it processes
+    int64_t r_lo = 0, r_hi = 0;
+    if (!segs.empty()) {
+      int64_t first = P, last = 0;
+      for (const Seg& sg : segs) {
+        first = std::min(first, sg.b);
+        last = std::max(last, sg.e);
+      }
+      const auto& pi = u.h_path_idx;
+      r_lo = std::max<int64_t>(0, (int64_t)(std::upper_bound(pi.begin(), pi.end(), first) - pi.begin()) - 1);
+      r_hi = std::min<int64_t>(u.n_uids, (int64_t)(std::lower_bound(pi.begin(), pi.end(), last) - pi.begin()));
+    }
     if (want_ie) {
       if (int rc = prepare_z()) return rc;
-      have_p0 = planes_current(c, jp.p0);                  // a kept join left them behind
+      have_p0 = planes_cover(c, jp.p0, r_lo, r_hi);        // a kept join left them behind
       if (!have_p0 && g.method == 1 && recipe_operands(c, jp.p0, &rec_a, &rec_z)) {
         // ... or it left the recipe: the kernel rebuilds a row's planes from the planes of the recipe's operands
-        if (int rc = ensure_planes(c, rec_a)) return rc;
+        // (of which a multi-device run may hold a range only: the rows the recipe of [r_lo, r_hi) names -- the
+        // producing join's paths0 rows, ascending)
+        int64_t a_lo = 0, a_hi = rec_a->nrows;
+        if (!planes_current(c, rec_a) && r_hi > r_lo && (size_t)r_hi <= jp.p0->rec->row0.cap) {
+          uint32_t ends[2] = {0, 0};
+          HIP_TRY(c, hipMemcpyAsync(&ends[0], jp.p0->rec->row0.p + r_lo, 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(&ends[1], jp.p0->rec->row0.p + (r_hi - 1), 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipStreamSynchronize(st));
+          a_lo = ends[0];
+          a_hi = (int64_t)ends[1] + 1;
+        }
+        if (!planes_cover(c, rec_a, a_lo, a_hi))
+          if (int rc = ensure_planes(c, rec_a)) return rc;
         if (int rc = ensure_planes(c, rec_z)) return rc;
-        use_rec = planes_current(c, rec_a) && planes_current(c, rec_z);
+        use_rec = planes_cover(c, rec_a, a_lo, a_hi) && planes_current(c, rec_z);
         have_p0 = use_rec;
       }
       if (!have_p0) {
-        if (int rc = ensure_planes(c, jp.p0)) return rc;   // from its bit lists
+        if (int rc = ensure_planes(c, jp.p0)) return rc;   // from its bit lists (all rows)
         have_p0 = planes_current(c, jp.p0);
       }
       if (!have_p0 || !have_pz) want_ie = false;   // the planes do not fit in device memory: delta streaming (gcre_sparse.hip)
@@ -1070,7 +1123,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             const double dense_cost = 2.0 * g.Wp * g.method * (double)g.K * 2.0 / 65.0;
             if (ie_cost >= dense_cost) { res_planes_ok = false; break; }
           }
-          if (!scored && !res_planes) {   // rows of another shard that only needed their recipe entries
+          if (!scored && !(res_planes && cb < pl_e && cb + n > pl_b)) {   // rows of another shard that only needed their recipe entries
             ran_sparse = true;
             break;
           }
@@ -1078,7 +1131,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           IeArgs ia{};
           int64_t nseg_scored = 0;
-          if (int rc = sparse_segments(c, u, cb, n, cb + s0, cb + s1, &ia.segs, &ia.nsegs, &nseg_scored)) return rc;
+          if (int rc = sparse_segments(c, u, cb, n, cb + s0, cb + s1, res_planes ? pl_b : cb + s0, res_planes ? pl_e : cb + s1,
+                                       &ia.segs, &ia.nsegs, &nseg_scored))
+            return rc;
           ia.mt = w_mt;
           ia.tot = c->d_tot.p;
           ia.rowz = rcp ? rcp->rowz.p + cb : c->d_rowz.p;
@@ -1162,13 +1217,14 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             // they find seeds the thresholds the pruned kernel starts from.  Joins of a few thousand paths run here whole.
             // (the scored segments lead the table.)  The general kernel is several times slower per path: a short
             // shard gives it an eighth of its segments, not all of them.
-            const int64_t n_warm = std::min<int64_t>(nseg_scored, std::min<int64_t>(std::max<int64_t>(2048, nseg_scored / 1024),
+            const int64_t warm_min = c->ie_warm_segs;
+            const int64_t n_warm = std::min<int64_t>(nseg_scored, std::min<int64_t>(std::max<int64_t>(warm_min, nseg_scored / 1024),
                                                                                     std::max<int64_t>(256, nseg_scored / 8)));
             IeArgs wa = ia;
             wa.seg_end = n_warm;
             while (wa.waves_per_xcd > 4 && n_warm < (int64_t)8 * wa.waves_per_xcd)
               wa.waves_per_xcd = std::max(4, (wa.waves_per_xcd / 2 / 4) * 4);
-            HIP_TRY(c, launch_null_ie(wa, g.method, planes, true, st));
+            if (n_warm > 0) HIP_TRY(c, launch_null_ie(wa, g.method, planes, true, st));
             ia.seg_begin = n_warm;
           }
           if (ia.seg_begin < ia.seg_end) {
@@ -1242,7 +1298,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           SparseArgs sp{};
           int64_t nseg_scored = 0;
-          if (int rc = sparse_segments(c, u, cb, n, cb, cb + n, &sp.segs, &sp.nsegs, &nseg_scored)) return rc;
+          if (int rc = sparse_segments(c, u, cb, n, cb, cb + n, cb, cb + n, &sp.segs, &sp.nsegs, &nseg_scored)) return rc;
           sp.mt = w_mt;
           sp.tot = c->d_tot.p;
           sp.loff0 = jp.p0->d_loff;
@@ -1359,6 +1415,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       jp.res->max_known = true;
     }
     keep_planes_done = res_planes && res_planes_ok && g.K > 0;
+    keep_planes_lo = pl_b;
+    keep_planes_hi = pl_e;
     keep_max_tot = join_max_tot;
     if (ie_ran && hinted) c->prof.ie_hinted_joins++;
     if (ie_ran && have_p0) c->prof.ie_plane_joins++;
@@ -1368,6 +1426,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     // the kept rows leave with their count planes: the next level's N0 (gcre_ie.hip)
     jp.res->planes_epoch = c->mask_epoch;
     jp.res->planes_valid = true;
+    jp.res->planes_lo = keep_planes_lo;
+    jp.res->planes_hi = keep_planes_hi;
     jp.res->max_bits = (keep_max_tot + 3u) & ~3u;
     jp.res->max_known = true;
   }
@@ -1476,6 +1536,7 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   if (const char* e = std::getenv("GCRE_NULL_KERNEL"))
     c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : !std::strcmp(e, "ie") ? 3 : 0;
   if (const char* e = std::getenv("GCRE_IE_PRUNE")) c->ie_prune = std::atoi(e) != 0;
+  if (const char* e = std::getenv("GCRE_IE_WARM")) c->ie_warm_segs = std::min(std::max(std::atoi(e), 1), 1 << 20);
   if (const char* e = std::getenv("GCRE_IE_BATCH")) c->ie_batch = std::min(std::max(std::atoi(e), 1), 4096);
   if (const char* e = std::getenv("GCRE_PLANES_OUT_MAX_MB")) c->planes_out_max = (size_t)std::max(0ll, std::atoll(e)) << 20;
   if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));
@@ -1843,7 +1904,12 @@ int gcre_join(gcre_ctx* c, int path_length, const int32_t* uid_count, const int6
   if (!u) return c->last_code;
   JoinPlan jp{u, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
               opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
-  if (opts && opts->keep_ranged) { jp.keep_ranged = true; jp.keep_begin = opts->keep_begin; jp.keep_end = opts->keep_end; }
+  if (opts && opts->keep_ranged) {
+    jp.keep_ranged = opts->keep_ranged == 1;
+    jp.planes_ranged = opts->keep_ranged == 2;
+    jp.keep_begin = opts->keep_begin;
+    jp.keep_end = opts->keep_end;
+  }
   int rc = run_join(c, jp, out);
   free_uids(u);
   if (rc != GCRE_OK) gcre_result_free(out);
@@ -1898,7 +1964,12 @@ int gcre_join_uids(gcre_ctx* c, const gcre_uids* uids, const gcre_pathset* paths
   (void)hipSetDevice(c->device);
   JoinPlan jp{uids, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
               opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
-  if (opts && opts->keep_ranged) { jp.keep_ranged = true; jp.keep_begin = opts->keep_begin; jp.keep_end = opts->keep_end; }
+  if (opts && opts->keep_ranged) {
+    jp.keep_ranged = opts->keep_ranged == 1;
+    jp.planes_ranged = opts->keep_ranged == 2;
+    jp.keep_begin = opts->keep_begin;
+    jp.keep_end = opts->keep_end;
+  }
   int rc = run_join(c, jp, out);
   if (rc != GCRE_OK) gcre_result_free(out);
   return rc;

@@ -53,8 +53,10 @@ typedef struct {
 typedef struct {
   int32_t sharded;      /* 0: score every joined path (reference behaviour); 1: only [shard_begin, shard_end) */
   int32_t keep_ranged;  /* 0: kept path rows are produced in full, whatever the shard; 1: only rows [keep_begin, keep_end)
-                           and the scored shard are produced -- the rest of `res` is left untouched.  For multi-device runs:
-                           a device only needs the kept rows its own shards of the later joins read */
+                           and the scored shard are produced -- the rest of `res` is left untouched; 2: every row is
+                           produced, but only rows [keep_begin, keep_end) and the shard get their permutation count planes
+                           (what a later join needs of the rows it reads as paths0; any other use rebuilds them).  For
+                           multi-device runs: a device only needs the kept rows its own shards of the later joins read */
   int64_t shard_begin;  /* joined-path ordinal range scored on THIS device (may be empty). */
   int64_t shard_end;
   void* d_null_out;     /* optional device pointer to iterations floats: receives this shard's null maxima

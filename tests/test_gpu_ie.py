@@ -127,6 +127,54 @@ def test_sharded_plan_keeps_planes_for_every_row(method, monkeypatch):
         np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
 
 
+@pytest.mark.parametrize("method", ["method1", "method2"])
+@pytest.mark.parametrize("world", [2, 5])
+def test_ranks_keep_planes_only_for_the_rows_they_read(method, world, monkeypatch):
+    """gcre_join_opts.keep_ranged = 2 at levels 1 and 2: every row is written (later joins read them as paths1 and as
+    reduced operands) but a rank only computes count planes for the rows its own work on the next level reads as
+    paths0.  Every join still runs on resident planes, the merged results equal the one-shot run."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_CHUNK_PATHS", "1024")
+    p = sparse_problem(method, 11, K=150, L=4)
+    want = oracle.process_paths(p, order="canonical")
+    parts = []
+    for rank in range(world):
+        plan = api.ResidentPlan(p)
+        n1, n2 = plan.needed_rows("1a", rank, world), plan.needed_rows("2", rank, world)
+        assert n1 is not None and n2 is not None and plan.keep_mode("2") == 2 and plan.keep_mode("3") == 1
+        assert n2[1] - n2[0] < plan.uids["2"].total_paths          # a strict part of level 2 gets planes
+        parts.append(plan.run(rank=rank, world=world))
+        assert plan.last_profile["ie_plane_joins"] == 5             # no join fell back to bit lists
+        for lvl in ("1", "2"):                                      # ... and all rows of levels 1 and 2 are there
+            np.testing.assert_array_equal(plan.kept[lvl].to_numpy(), want[f"paths{lvl}"])
+        plan.close()
+    for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4)):
+        null = np.maximum.reduce([r[name].null for r in parts])
+        rows = [np.stack([r[name].scores, r[name].src, r[name].trg, r[name].cases, r[name].ctrls], axis=1) for r in parts]
+        best = dist.merge_topk(np.vstack(rows), p.top_k)
+        w = want[f"lst{lvl}"]
+        np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
+
+
+def test_a_partial_set_of_planes_is_never_trusted_beyond_its_rows(monkeypatch):
+    """A set whose planes cover a range only (keep_ranged = 2) and is then read in full -- as paths0 of an unsharded
+    join -- gets its planes rebuilt: results equal the oracle's."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    p = sparse_problem("method1", 13, K=130, L=3)
+    want = oracle.process_paths(p, order="canonical")
+    plan = api.ResidentPlan(p)
+    ex = plan.ex
+    p0, p1, res = plan.operands("1a")
+    total = plan.uids["1a"].total_paths
+    ex.join(plan.uids["1a"], p0, p1, res, shard=(0, total // 3), keep=(0, total // 2), keep_mode=2)
+    p0, p1, res = plan.operands("2")
+    r = ex.join(plan.uids["2"], p0, p1, res)        # reads every row of level 1 as paths0
+    np.testing.assert_array_equal(r.null.view(np.uint32), want["lst2"].null.view(np.uint32))
+    np.testing.assert_array_equal(r.scores, want["lst2"].scores)
+    plan.close()
+
+
 def test_arbitrary_table_prunes_exactly(monkeypatch):
     """The pruning ladder makes no assumption about the table's shape: a table with random cells (not valley-shaped,
     with zeros, huge values and -1 padding) gives the oracle's maxima."""
