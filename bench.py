@@ -7,7 +7,9 @@ One "step" = one pass of the hot path (the ProcessPaths join sequence, reference
 levels 1a, 1b, 2 .. path_length) over one synthetic problem whose inputs are already resident in HBM.
 For N > 1 it is launched by torch.distributed.run, one rank per GPU: every level's joined paths are sharded
 into N contiguous slices, each rank scores its slice, and the per-permutation null maxima (MAX all-reduce) and
-the top-k tables (all-gather + merge) are exchanged over RCCL.  Total work is fixed -> "strong" scaling.
+the top-k tables (all-gather + merge) are exchanged over RCCL.  Default "weak" scaling: the job runs the config's
+permutation count PER GPU (K = 10,000 x N at configs[2]: more GPUs buy a finer p-value floor in the same time), so the
+scores a GPU computes per pass do not depend on N; `--scaling strong` keeps K fixed instead (same results for any N).
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -197,6 +199,8 @@ def main():
     ap.add_argument("--method", default="", choices=["", "method1", "method2"], help="override the config's scoring method")
     ap.add_argument("--top-k", type=int, default=100)
     ap.add_argument("--seed", type=int, default=20261003)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = the config's permutations per GPU (K x N in total), strong = K in total")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + several ranks on one GPU is a rehearsal of the N > 1 path, not a measurement")
@@ -228,6 +232,9 @@ def main():
         cfg["edges"] = args.edges
     if args.perms:
         cfg["perms"] = args.perms
+    perms_per_gpu = cfg["perms"]
+    if args.scaling == "weak":
+        cfg["perms"] *= world
     prob, masks = build_inputs(cfg, args.seed, args.top_k)
 
     from geneticscre_amd import api
@@ -346,11 +353,12 @@ def main():
     line = {
         "metric": "path_x_permutation_scores_per_sec", "value": value, "unit": "scores/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[{cfg['idx']}] '{args.config}': synthetic STRINGdb-shaped signed network, "
                         f"{cfg['genes']} genes / {cfg['edges']} relations, {prob.n_cases}+{prob.n_ctrls} patients, "
-                        f"{K} permutations, path length {prob.path_length}, {prob.method}",
+                        f"{K} permutations, path length {prob.path_length}, {prob.method}"
+                        + (f" (weak scaling: {perms_per_gpu} permutations per GPU x {world} GPUs)" if world > 1 and args.scaling == "weak" else ""),
             "paths_per_level": {k: plan.uids[k].total_paths for k in plan.names},
             "scores_per_step": total_scores, "top_k": top_k, "seed": args.seed,
             "parallelism": f"paths sharded over {world} GPU(s), RCCL max-all-reduce + top-k all-gather per level",

@@ -1217,12 +1217,14 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             // they find seeds the thresholds the pruned kernel starts from.  Joins of a few thousand paths run here whole.
             // (the scored segments lead the table.)  The general kernel is several times slower per path: a short
             // shard gives it an eighth of its segments, not all of them.
-            const int64_t warm_min = c->ie_warm_segs;
+            // every tile warms up on its own permutations: with many tiles the slice gets shorter (its cost is per tile)
+            const int64_t warm_min = std::max<int64_t>(256, (int64_t)c->ie_warm_segs * 8 / std::max(nkt_sp, 8));
             const int64_t n_warm = std::min<int64_t>(nseg_scored, std::min<int64_t>(std::max<int64_t>(warm_min, nseg_scored / 1024),
                                                                                     std::max<int64_t>(256, nseg_scored / 8)));
             IeArgs wa = ia;
             wa.seg_end = n_warm;
-            while (wa.waves_per_xcd > 4 && n_warm < (int64_t)8 * wa.waves_per_xcd)
+            // a wave walks its tiles one after the other: keep enough waves that each gets about four (segment, tile) items
+            while (wa.waves_per_xcd > 4 && n_warm * nkt_sp < (int64_t)8 * wa.waves_per_xcd * 4)
               wa.waves_per_xcd = std::max(4, (wa.waves_per_xcd / 2 / 4) * 4);
             if (n_warm > 0) HIP_TRY(c, launch_null_ie(wa, g.method, planes, true, st));
             ia.seg_begin = n_warm;

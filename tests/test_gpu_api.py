@@ -172,7 +172,8 @@ def test_bench_two_ranks_reproduce_one_rank(tmp_path):
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--backend", "gloo", *common], capture_output=True, text=True, env=env, timeout=600)
+                          "--gpus", "2", "--backend", "gloo", "--scaling", "strong", *common], capture_output=True, text=True,
+                         env=env, timeout=600)
     assert two.returncode == 0, two.stderr[-2000:]
     a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])

@@ -6,8 +6,11 @@ import bench
 from geneticscre_amd import api
 
 rank, world = int(sys.argv[1]), int(sys.argv[2])
-prob, masks = bench.build_inputs(bench.CONFIGS["roofline"], 20261003, 100)
-plan = api.ResidentPlan(prob, packed_masks=masks)
+cfg = dict(bench.CONFIGS["roofline"])
+if os.environ.get("WEAK") == "1":      # weak scaling: 10,000 permutations per rank
+    cfg["perms"] *= world
+prob, masks = bench.build_inputs(cfg, 20261003, 100)
+plan = api.ResidentPlan(prob, packed_masks=masks, mask_seed=None if masks is not None else 1)
 for _ in range(3):
     t0 = time.perf_counter()
     plan.run(rank, world)
