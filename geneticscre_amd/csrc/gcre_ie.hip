@@ -489,7 +489,11 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
   __shared__ u32 wq_state[kIeWaves][8];
   WorkQueue wq;
   wq.st = wq_state[wave];
-  wq.init(a.queue, (u32)((a.seg_end - a.seg_begin + a.batch - 1) / a.batch), 8u, (u32)a.nkt);
+  {
+    const u32 nb = (u32)((a.seg_end - a.seg_begin + a.batch - 1) / a.batch);
+    if (a.queue_mode == 0) wq.init(a.queue, nb, 8u, (u32)a.nkt);
+    else wq.init(a.queue, nb * (u32)a.nkt, 8u, 1u);
+  }
   {
     wq.select(blockIdx.x & 7u);   // workgroups are dealt round the XCDs: blocks b and b + 8 share an L2
   }
@@ -505,8 +509,17 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
       continue;
     }
     ticket = wq.take(lane);   // the next ticket is on its way while this batch is worked on
-    const int kt = (int)(work / q_n);
-    const i64 s_lo = a.seg_begin + (i64)(wq.get(1) + (work - (u32)kt * q_n)) * a.batch;
+    int kt;
+    u32 bidx;
+    if (a.queue_mode == 0) {   // the queue owns an eighth of the segments, in every tile
+      kt = (int)(work / q_n);
+      bidx = wq.get(1) + (work - (u32)kt * q_n);
+    } else {                   // the queue owns an eighth of the (tile, batch) sequence
+      const u32 item = wq.get(1) + work, nb = wq.get(3) / (u32)a.nkt;
+      kt = (int)(item / nb);
+      bidx = item - (u32)kt * nb;
+    }
+    const i64 s_lo = a.seg_begin + (i64)bidx * a.batch;
     const i64 s_hi = s_lo + a.batch < a.seg_end ? s_lo + a.batch : a.seg_end;
     if (kt != cur_kt) {
       flush_tile();
@@ -904,7 +917,11 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
   __shared__ u32 wq_state[kIeWaves][8];
   WorkQueue wq;
   wq.st = wq_state[wave];
-  wq.init(a.queue, (u32)((a.seg_end - a.seg_begin + a.batch - 1) / a.batch), 8u, (u32)a.nkt);
+  {
+    const u32 nb = (u32)((a.seg_end - a.seg_begin + a.batch - 1) / a.batch);
+    if (a.queue_mode == 0) wq.init(a.queue, nb, 8u, (u32)a.nkt);
+    else wq.init(a.queue, nb * (u32)a.nkt, 8u, 1u);
+  }
   {
     wq.select(blockIdx.x & 7u);   // workgroups are dealt round the XCDs: blocks b and b + 8 share an L2
   }
@@ -920,8 +937,17 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
       continue;
     }
     ticket = wq.take(lane);   // the next ticket is on its way while this batch is worked on
-    const int kt = (int)(work / q_n);
-    const i64 s_lo = a.seg_begin + (i64)(wq.get(1) + (work - (u32)kt * q_n)) * a.batch;
+    int kt;
+    u32 bidx;
+    if (a.queue_mode == 0) {   // the queue owns an eighth of the segments, in every tile
+      kt = (int)(work / q_n);
+      bidx = wq.get(1) + (work - (u32)kt * q_n);
+    } else {                   // the queue owns an eighth of the (tile, batch) sequence
+      const u32 item = wq.get(1) + work, nb = wq.get(3) / (u32)a.nkt;
+      kt = (int)(item / nb);
+      bidx = item - (u32)kt * nb;
+    }
+    const i64 s_lo = a.seg_begin + (i64)bidx * a.batch;
     const i64 s_hi = s_lo + a.batch < a.seg_end ? s_lo + a.batch : a.seg_end;
     if (kt != cur_kt) {
       flush_tile();
