@@ -109,7 +109,6 @@ struct gcre_ctx {
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
   int ie_warm_segs = 2048;           // least number of segments in the warm-up slice (GCRE_IE_WARM)
-  int ie_queue_mode = 1;             // GCRE_IE_QMODE
   int ie_batch = 2;                  // segments per ticket (GCRE_IE_BATCH)
   uint32_t* d_queue = nullptr;       // ticket counters of the pruned kernels' work queues (8 x 16 words)
   uint32_t* d_max_tot = nullptr;     // 8 words: largest carrier total of the chunk, "reduced operand is wrong", overlap lists,
@@ -1233,7 +1232,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (ia.seg_begin < ia.seg_end) {
             ia.queue = c->d_queue;
             ia.batch = c->ie_batch;
-            ia.queue_mode = c->ie_queue_mode;
             HIP_TRY(c, hipMemsetAsync(ia.queue, 0, 8 * 16 * 4, st));
             HIP_TRY(c, launch_null_ie(ia, g.method, planes, c->d_ladder == nullptr, st));
           }
@@ -1541,7 +1539,6 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
     c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : !std::strcmp(e, "ie") ? 3 : 0;
   if (const char* e = std::getenv("GCRE_IE_PRUNE")) c->ie_prune = std::atoi(e) != 0;
   if (const char* e = std::getenv("GCRE_IE_WARM")) c->ie_warm_segs = std::min(std::max(std::atoi(e), 1), 1 << 20);
-  if (const char* e = std::getenv("GCRE_IE_QMODE")) c->ie_queue_mode = std::atoi(e) != 0;
   if (const char* e = std::getenv("GCRE_IE_BATCH")) c->ie_batch = std::min(std::max(std::atoi(e), 1), 4096);
   if (const char* e = std::getenv("GCRE_PLANES_OUT_MAX_MB")) c->planes_out_max = (size_t)std::max(0ll, std::atoll(e)) << 20;
   if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));

@@ -131,7 +131,6 @@ struct IeArgs {
   int64_t seg_begin, seg_end;        // slice of the segment table this launch walks
   uint32_t score_begin, score_end;   // joined paths of the launch outside [begin, end) only produce planes
   int batch;                         // segments per ticket
-  int queue_mode;                    // 0: a queue owns an eighth of the segments in every tile; 1: an eighth of the (tile, batch) sequence
   uint32_t* queue;                   // pruned kernels: the eight ticket counters of the launch (16 words apart), zero on entry
   uint32_t score_segs;               // the same range in segments: the table's first score_segs segments (they do not straddle)
   int nkt, waves_per_xcd, K;
