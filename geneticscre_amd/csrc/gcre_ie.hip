@@ -810,9 +810,11 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
 // (k_build_ladder2, four borrow-chain tests); what fails both rectangles is looked up exactly: both cells gathered in
 // f64, added, rounded, clamped at 0.
 // ------------------------------------------------------------------------------------------------
-template <int L, bool OUT>
-__global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
+template <int L, int GZ, bool OUT>
+__global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L <= 10 ? 4 : 3))) void k_null_ie_m2(const IeArgs a) {
   constexpr int LP = (L + 3) / 4 * 4;
+  constexpr int LZ = 4 * GZ;   // planes of an added row (GZ groups; the launch picks GZ >= a.gz)
+  static_assert(LZ <= LP, "added rows have no more planes than joined paths");
   static_assert(L >= 8 && L <= 16, "8 to 16 counter planes");
   typedef u32 __attribute__((ext_vector_type(8))) u32x8;
   __shared__ u32 nmax_lds[kIeWaves][32 * 64];
@@ -961,80 +963,98 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
       for (int h = 0; h < 2; h++)
         load_groups(B[h], a.planes0, ((u64)kt * (u64)a.rows0 + (u64)row0 * 2 + h) * (u64)a.g0, a.g0);
 
-      for (u32 t = 0; t < npaths; t++) {
-        u32 C[2][L];
+      // ---- the joined paths of the segment, half by half, software-pipelined one half ahead (as k_null_ie_m1): the
+      // mask rows and planes of the next half are in flight while this one is added up.  (+) halves use buffer A,
+      // (-) halves buffer B; the last path is simply requested twice. ----
+      const u32 last = npaths - 1u;
+      auto at = [&](u32 t2) -> u32 { return t2 < last ? t2 : last; };
+      auto issue = [&](int h, u32 t2, const u32x8 offs, u32 (&yy)[8], u32 (&ZZ)[LZ]) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const u32 r0 = rdlane(infov[h], t);
-          const u32 len = r0 & ~7u;
-          const bool overlap = (r0 & 1u) != 0u;
-          const u32x8 offs = slots[t * 2 + h];
-          u32 y[8];
+        for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+        if (rdlane(infov[h], t2) & 1u) {   // overlap lists only
+          const u32x4* src = (const u32x4*)(a.planesz + (u64)rdlane(zunit[h], t2) * 256u) + lane;
 #pragma unroll
-          for (int j = 0; j < 8; j++) y[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
-          u32 Z[LP];
-          if (overlap) {
-            load_groups(Z, a.planesz, (u64)rdlane(zunit[h], t), a.gz);
-          } else {
-#pragma unroll
-            for (int l = 0; l < LP; l++) Z[l] = 0u;
+          for (int j = 0; j < GZ; j++) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (j < a.gz) v = src[j * 64];
+            ZZ[4 * j + 0] = v.x; ZZ[4 * j + 1] = v.y; ZZ[4 * j + 2] = v.z; ZZ[4 * j + 3] = v.w;
           }
-          u32 S[L];
-          {
-            u32 S4[4];
-            sum8(y, S4);
+        }
+      };
+      u32 C[2][L];
+      auto compute = [&](int h, u32 t, const u32 (&y)[8], const u32 (&Z)[LZ]) {
+        const u32 r0 = rdlane(infov[h], t);
+        const u32 len = r0 & ~7u;
+        const bool overlap = (r0 & 1u) != 0u;
+        u32 S[L];
+        {
+          u32 S4[4];
+          sum8(y, S4);
 #pragma unroll
-            for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
-          }
-          if (len > 8u) {   // long list (rare): further blocks of 8 entries
-            const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + rdlane(lovv[h], t));
-            for (u32 p = 0u; p + 8u < len; p += 8u) {
-              const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
-              u32 yy[8], s4[4];
+          for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
+        }
+        if (len > 8u) {   // long list (rare): further blocks of 8 entries
+          const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + rdlane(lovv[h], t));
+          for (u32 p = 0u; p + 8u < len; p += 8u) {
+            const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
+            u32 yy[8], s4[4];
 #pragma unroll
-              for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o8[j], 0);
-              sum8(yy, s4);
-              u32 cy = 0u;
-#pragma unroll
-              for (int l = 0; l < L; l++) {
-                const u32 sv = S[l];
-                const u32 add = (l < 4) ? s4[l < 4 ? l : 0] : 0u;
-                S[l] = xor3(sv, add, cy);
-                cy = majority(sv, add, cy);
-              }
-            }
-          }
-          if (overlap) {   // C = B + Nz - S
-            u32 cy = 0u, bw = 0u;
-#pragma unroll
-            for (int l = 0; l < L; l++) {
-              const u32 s1_ = xor3(B[h][l], Z[l], cy);
-              cy = majority(B[h][l], Z[l], cy);
-              C[h][l] = xor3(s1_, S[l], bw);
-              bw = borrow3(s1_, S[l], bw);
-            }
-          } else {         // C = B + S
+            for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o8[j], 0);
+            sum8(yy, s4);
             u32 cy = 0u;
 #pragma unroll
             for (int l = 0; l < L; l++) {
-              C[h][l] = xor3(B[h][l], S[l], cy);
-              cy = majority(B[h][l], S[l], cy);
-            }
-          }
-          if constexpr (OUT) {
-            const u64 rh = ((u64)a.out_first + first + t) * 2 + h;
-            u32x4* dst = (u32x4*)(a.planes_out + (((u64)kt * (u64)a.rows_out + rh) * (u64)a.go) * 256u) + lane;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              if (j < a.go) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (4 * j < L) v = u32x4{C[h][(4 * j) % L], (4 * j + 1 < L) ? C[h][(4 * j + 1) % L] : 0u,
-                                         (4 * j + 2 < L) ? C[h][(4 * j + 2) % L] : 0u, (4 * j + 3 < L) ? C[h][(4 * j + 3) % L] : 0u};
-                dst[j * 64] = v;
-              }
+              const u32 sv = S[l];
+              const u32 add = (l < 4) ? s4[l < 4 ? l : 0] : 0u;
+              S[l] = xor3(sv, add, cy);
+              cy = majority(sv, add, cy);
             }
           }
         }
+        if (overlap) {   // C = B + Nz - S
+          u32 cy = 0u, bw = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            const u32 zl = (l < LZ) ? Z[l < LZ ? l : 0] : 0u;
+            const u32 s1_ = xor3(B[h][l], zl, cy);
+            cy = majority(B[h][l], zl, cy);
+            C[h][l] = xor3(s1_, S[l], bw);
+            bw = borrow3(s1_, S[l], bw);
+          }
+        } else {         // C = B + S
+          u32 cy = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            C[h][l] = xor3(B[h][l], S[l], cy);
+            cy = majority(B[h][l], S[l], cy);
+          }
+        }
+        if constexpr (OUT) {
+          const u64 rh = ((u64)a.out_first + first + t) * 2 + h;
+          u32x4* dst = (u32x4*)(a.planes_out + (((u64)kt * (u64)a.rows_out + rh) * (u64)a.go) * 256u) + lane;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (j < a.go) {
+              u32x4 v = {0u, 0u, 0u, 0u};
+              if (4 * j < L) v = u32x4{C[h][(4 * j) % L], (4 * j + 1 < L) ? C[h][(4 * j + 1) % L] : 0u,
+                                       (4 * j + 2 < L) ? C[h][(4 * j + 2) % L] : 0u, (4 * j + 3 < L) ? C[h][(4 * j + 3) % L] : 0u};
+              dst[j * 64] = v;
+            }
+          }
+        }
+      };
+      u32 yA[8], yB[8], ZA[LZ], ZB[LZ];
+#pragma unroll
+      for (int l = 0; l < LZ; l++) ZA[l] = ZB[l] = 0u;
+      u32x8 oA = slots[0], oB = slots[1];
+      issue(0, 0u, oA, yA, ZA);
+      for (u32 t = 0; t < npaths; t++) {
+        issue(1, t, oB, yB, ZB);
+        oA = slots[at(t + 1u) * 2u];
+        compute(0, t, yA, ZA);
+        issue(0, at(t + 1u), oA, yA, ZA);
+        oB = slots[at(t + 1u) * 2u + 1u];
+        compute(1, t, yB, ZB);
         // ---- a permutation is safe when (F <= ha and G <= hb) or (F <= hb and G <= ha): ha + hb <= theta ----
         const u32 pa = outside(C[0], rdlane(lha[0], t)), pb = outside(C[0], rdlane(lhb[0], t));
         const u32 na = outside(C[1], rdlane(lha[1], t)), nb_ = outside(C[1], rdlane(lhb[1], t));
@@ -1081,6 +1101,13 @@ __global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m2(const IeArgs a) {
   else if (planes <= 12) { EXPR(2, 12); }   \
   else { EXPR(2, 16); }
 
+// pruned signed-method kernel: counter planes of the joined paths x plane groups of the added rows
+#define GCRE_IE_M2P(EXPR)                                                                  \
+  if (planes <= 8) { EXPR(8, 2); }                                                         \
+  else if (planes <= 10) { if (a.gz <= 2) { EXPR(10, 2); } else { EXPR(10, 3); } }         \
+  else if (planes <= 12) { if (a.gz <= 2) { EXPR(12, 2); } else { EXPR(12, 3); } }         \
+  else { if (a.gz <= 2) { EXPR(16, 2); } else { EXPR(16, 4); } }
+
 #define GCRE_IE_M1_OR(EXPR, LL, GG)                                                  \
   if (out) { if (rec) { EXPR(LL, GG, true, true); } else { EXPR(LL, GG, true, false); } }   \
   else { if (rec) { EXPR(LL, GG, false, true); } else { EXPR(LL, GG, false, false); } }
@@ -1120,8 +1147,8 @@ hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general,
 #undef GCRE_LAUNCH
   } else if (method == 2 && !general) {
     const bool out = a.planes_out != nullptr;
-#define GCRE_LAUNCH2(LL) if (out) hipLaunchKernelGGL((k_null_ie_m2<LL, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((k_null_ie_m2<LL, false>), grid, block, 0, stream, a)
-    if (planes <= 8) { GCRE_LAUNCH2(8); } else if (planes <= 10) { GCRE_LAUNCH2(10); } else if (planes <= 12) { GCRE_LAUNCH2(12); } else { GCRE_LAUNCH2(16); }
+#define GCRE_LAUNCH2(LL, GG) if (out) hipLaunchKernelGGL((k_null_ie_m2<LL, GG, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((k_null_ie_m2<LL, GG, false>), grid, block, 0, stream, a)
+    GCRE_IE_M2P(GCRE_LAUNCH2)
 #undef GCRE_LAUNCH2
   } else {
 #define GCRE_LAUNCH(MM, LL) hipLaunchKernelGGL((k_null_ie<MM, LL>), grid, block, 0, stream, a)
@@ -1139,8 +1166,9 @@ int ie_max_waves_per_cu(int method, int planes, int gz, bool out, bool rec) {
     GCRE_IE_M1(GCRE_OCC)
 #undef GCRE_OCC
   } else {
-#define GCRE_OCC2(LL) e = out ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m2<LL, true>, 64 * kIeWaves, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m2<LL, false>, 64 * kIeWaves, 0)
-    if (planes <= 8) { GCRE_OCC2(8); } else if (planes <= 10) { GCRE_OCC2(10); } else if (planes <= 12) { GCRE_OCC2(12); } else { GCRE_OCC2(16); }
+    struct { int gz; } a{gz};
+#define GCRE_OCC2(LL, GG) e = out ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m2<LL, GG, true>, 64 * kIeWaves, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m2<LL, GG, false>, 64 * kIeWaves, 0)
+    GCRE_IE_M2P(GCRE_OCC2)
 #undef GCRE_OCC2
   }
   if (e != hipSuccess || blocks < 1) blocks = 1;
