@@ -408,7 +408,7 @@ __device__ __forceinline__ void sum8(const u32 (&r)[8], u32 (&s)[4]) {
 }
 
 template <int L, int GZ, bool OUT, bool REC>
-__global__ __launch_bounds__(64 * kIeWaves) void k_null_ie_m1(const IeArgs a) {
+__global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L <= 12 ? 4 : 3))) void k_null_ie_m1(const IeArgs a) {
   // L counter planes (any even number: the arithmetic runs over exactly L); plane arrays come in groups of 4
   constexpr int LP = (L + 3) / 4 * 4;
   static_assert(L >= 8 && L <= 16 && GZ >= 2 && 4 * GZ <= LP, "planes come in groups of 4");
