@@ -1466,12 +1466,13 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
     u64 xw[M][NW], zw[M][NW];  // NIT > 0: the row's words, kept for the list pass
 #pragma unroll
     for (int h = 0; h < M; h++) cc[h] = dv[h] = 0u;
+    u64 stray = 0;   // excess bits outside paths0[idx]: the hint does not describe this uid
     auto tally = [&](int h, int k, u64 xk, u64 zk, u64 uk, u64 cm) {
       const u64 j = xk | zk;
       if (out) out[h * Wp + k] = j;
-      if (uk & ~xk) my_bad = true;
-      cc[h] += (u32)__popcll(j & cm) | ((u32)__popcll(j & ~cm) << 16);
-      dv[h] += (u32)__popcll(zk & ~xk) | ((u32)__popcll(zk & xk) << 16);
+      stray |= uk & ~xk;
+      cc[h] += (u32)__popcll(j & cm) | ((u32)__popcll(j) << 16);          // among the cases | all (controls by difference)
+      dv[h] += (u32)__popcll(zk & ~xk) | ((u32)__popcll(zk) << 16);       // new | all of z (overlap by difference)
     };
     if constexpr (NIT > 0) {
       u64 uw[M][NW];
@@ -1501,14 +1502,15 @@ __global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
         for (int h = 0; h < M; h++) tally(h, k, x[h * Wp + k], zh[h][k], uu ? uh[h][k] : 0, cm);
       }
     }
+    if (stray) my_bad = true;
     u32 tot[M], mode[M], len[M], inc[M], inm[M];
 #pragma unroll
     for (int h = 0; h < M; h++) {
       const u32 c = row_total(cc[h], lane), d = row_total(dv[h], lane);
       inc[h] = c & 0xffffu;      // carriers among the cases
-      inm[h] = c >> 16;          // carriers among the controls
-      tot[h] = inc[h] + inm[h];
-      const u32 dl = d & 0xffffu, ov = d >> 16;
+      tot[h] = c >> 16;
+      inm[h] = tot[h] - inc[h];  // carriers among the controls
+      const u32 dl = d & 0xffffu, ov = (d >> 16) - dl;
       mode[h] = (a.ie_bias >= 0 && ov + (u32)a.ie_bias < dl) ? 1u : 0u;
       len[h] = mode[h] ? ov : dl;
       if (active && sl == 0) {
