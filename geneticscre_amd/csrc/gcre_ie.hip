@@ -1666,9 +1666,11 @@ hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {
   const int nit = (a.Wp + 15) / 16;
 #define GCRE_ST(MM, NN) hipLaunchKernelGGL((k_stats_ie<MM, NN>), grid, block, 0, stream, a)
   if (method == 1) {
-    if (nit <= 2) GCRE_ST(1, 2); else if (nit <= 4) GCRE_ST(1, 4); else if (nit <= 6) GCRE_ST(1, 6); else if (nit <= 8) GCRE_ST(1, 8); else GCRE_ST(1, 0);
+    if (nit <= 1) GCRE_ST(1, 1); else if (nit <= 2) GCRE_ST(1, 2); else if (nit <= 3) GCRE_ST(1, 3); else if (nit <= 4) GCRE_ST(1, 4);
+    else if (nit <= 5) GCRE_ST(1, 5); else if (nit <= 6) GCRE_ST(1, 6); else if (nit <= 8) GCRE_ST(1, 8); else GCRE_ST(1, 0);
   } else {
-    if (nit <= 2) GCRE_ST(2, 2); else if (nit <= 4) GCRE_ST(2, 4); else GCRE_ST(2, 0);
+    if (nit <= 1) GCRE_ST(2, 1); else if (nit <= 2) GCRE_ST(2, 2); else if (nit <= 3) GCRE_ST(2, 3); else if (nit <= 4) GCRE_ST(2, 4);
+    else if (nit <= 5) GCRE_ST(2, 5); else GCRE_ST(2, 0);
   }
 #undef GCRE_ST
   return hipGetLastError();
