@@ -1414,7 +1414,7 @@ __device__ __forceinline__ u32 row_total(u32 v, int lane) { return row_last(row_
 // NIT > 0: the row fits NIT passes of 16 lanes (Wp <= 16 * NIT): all its words are loaded up front, in flight
 // together, and stay in registers for the list pass.  NIT == 0: any width, words are read again for the lists.
 template <int M, int NIT>
-__global__ __launch_bounds__(256) void k_stats_ie(const StatsArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((M == 1 && NIT > 0 && NIT <= 5) ? 6 : 4))) void k_stats_ie(const StatsArgs a) {
   constexpr int NW = NIT > 0 ? NIT : 1;
   const int lane = threadIdx.x & 63;
   const int sl = lane & 15;
