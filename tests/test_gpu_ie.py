@@ -175,6 +175,18 @@ def test_a_partial_set_of_planes_is_never_trusted_beyond_its_rows(monkeypatch):
     plan.close()
 
 
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_many_permutation_tiles_few_segments(method, monkeypatch):
+    """Ten 2048-permutation tiles (the last one partial) over joins of a few hundred segments: the work queues hand
+    whole tiles to some XCDs and fractions to others, most waves steal, every wave changes tile several times."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    p = sparse_problem(method, 21, K=18500, L=4, genes=40, edges=110)
+    got = api.process_paths(p)
+    want = oracle.process_paths(p, order="canonical", nthreads=8)
+    check_levels(got, want, range(1, 5))
+    assert got["profile"]["ie_launches"] >= 5
+
+
 def test_arbitrary_table_prunes_exactly(monkeypatch):
     """The pruning ladder makes no assumption about the table's shape: a table with random cells (not valley-shaped,
     with zeros, huge values and -1 padding) gives the oracle's maxima."""
