@@ -123,7 +123,7 @@ struct gcre_ctx {
   int win_k0 = 0, win_K = 0;
 
   // per-join scratch
-  DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk;
+  DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk, d_rec_segs;
   DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan, d_excess;
   DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz, d_ie_scratch, d_linfo, d_lover, d_dover;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
@@ -1164,6 +1164,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             ia.rec_rows_z = (uint32_t)rec_z->nrows;
             ia.rec_ga = rec_a->plane_groups;
             ia.rec_gz = rec_z->plane_groups;
+            // the recipe entries of every segment's row, next to the segment table (no load depends on row0 any more)
+            HIP_TRY(c, c->d_rec_segs.reserve((size_t)std::max<int64_t>(ia.nsegs, 1) * kRecSegWords));
+            HIP_TRY(c, launch_fill_rec_segs(ia.segs, ia.nsegs, r0->row0.p, r0->rowz.p, r0->linfo.p, r0->lover.p, r0->slot.p,
+                                            c->d_rec_segs.p, st));
+            ia.rec_segs = c->d_rec_segs.p;
           }
           ia.t32 = c->d_t32;
           ia.d64 = c->d_dmax;
@@ -1574,7 +1579,7 @@ void gcre_destroy(gcre_ctx* c) {
                   (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot, (void*)c->d_queue, (void*)c->d_ladder})
     if (p) (void)hipFree(p);
   for (auto* b : {&c->d_row0, &c->d_row1, &c->d_tot, &c->d_cases, &c->d_ctrls, &c->d_sel, &c->d_small, &c->d_chunk,
-                  &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})
+                  &c->d_rec_segs, &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})
     b->release();
   c->d_key.release();
   c->d_wkey.release();

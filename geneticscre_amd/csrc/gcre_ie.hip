@@ -515,10 +515,50 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
       since = 0;
       period = 1;
     }
+    // The table entries of a segment -- (row0, first, n) and, with a recipe, the twelve words k_fill_rec_segs gathered
+    // for it -- are wave-uniform.  Inside a batch they are fetched one segment ahead into one VGPR (lane l = word l)
+    // and moved to scalar registers with v_readlane when their turn comes: the first segment of a batch pays the
+    // scalar-load round trip, the others start their plane loads at once.
+    u32 nextv = 0u;
+    bool have_next = false;
     for (i64 sidx = s_lo; sidx < s_hi; sidx++) {
-      const u32 row0 = segs[sidx].row0;
-      const u32 first = segs[sidx].first;
-      const u32 npaths = segs[sidx].n;
+      u32 row0, first, npaths;
+      u32 rc_a = 0u, rc_z = 0u, rc_info = 0u, rc_lov = 0u;
+      typedef u32 __attribute__((ext_vector_type(8))) u32x8;
+      u32x8 rc_o = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      if (have_next) {
+        row0 = rdlane(nextv, 0);
+        first = rdlane(nextv, 1);
+        npaths = rdlane(nextv, 2);
+        if constexpr (REC) {
+          rc_a = rdlane(nextv, 4);
+          rc_z = rdlane(nextv, 5);
+          rc_info = rdlane(nextv, 6);
+          rc_lov = rdlane(nextv, 7);
+#pragma unroll
+          for (int j = 0; j < 8; j++) rc_o[j] = rdlane(nextv, 8 + j);
+        }
+      } else {
+        row0 = segs[sidx].row0;
+        first = segs[sidx].first;
+        npaths = segs[sidx].n;
+        if constexpr (REC) {
+          const u32 GCRE_CONSTANT* rs = (const u32 GCRE_CONSTANT*)a.rec_segs + (u64)sidx * kRecSegWords;
+          rc_a = rs[0];
+          rc_z = rs[1];
+          rc_info = rs[2];
+          rc_lov = rs[3];
+          rc_o = *(const u32x8 GCRE_CONSTANT*)(rs + 4);
+        }
+      }
+      have_next = sidx + 1 < s_hi;
+      if (have_next) {
+        const u32* src = (const u32*)a.segs + (u64)(sidx + 1) * 3u + (u32)(lane < 3 ? lane : 0);
+        if constexpr (REC) {
+          if (lane >= 4 && lane < 16) src = a.rec_segs + (u64)(sidx + 1) * kRecSegWords + (u32)(lane - 4);
+        }
+        nextv = *src;
+      }
       GCRE_TM_MARK(ts0);
       if (a.lad_mode == 0 && ++since >= period) {
         exchange();
@@ -538,7 +578,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
       const u32 lhv = a.ladder[((u64)sidx < (u64)a.score_segs ? lad_base : lad_keep) + totv];
       // the first 8 entries of every list (lists are padded to 8: most lists end there) are wave-uniform: they come
       // through the scalar cache, one s_load_dwordx8 per path, fetched one path ahead of the loads that use them
-      typedef u32 __attribute__((ext_vector_type(8))) u32x8;
       const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 8u);
       auto issue = [&](u32 t2, const u32x8 offs, u32 (&yy)[8], u32 (&ZZ)[4 * GZ]) {
 #pragma unroll
@@ -572,12 +611,8 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
       if constexpr (!REC) {
         load_groups(B, a.planes0, ((u64)kt * (u64)a.rows0 + (u64)row0) * (u64)a.g0, a.g0);
       } else {
-        const u32 GCRE_CONSTANT* r_row0 = (const u32 GCRE_CONSTANT*)a.rec_row0;
-        const u32 GCRE_CONSTANT* r_rowz = (const u32 GCRE_CONSTANT*)a.rec_rowz;
-        const u32 GCRE_CONSTANT* r_info = (const u32 GCRE_CONSTANT*)a.rec_linfo;
-        const u32 GCRE_CONSTANT* r_lov = (const u32 GCRE_CONSTANT*)a.rec_lover;
-        const u32 ra = r_row0[row0], rz = r_rowz[row0] & 0x7fffffffu, rinfo = r_info[row0];
-        const u32x8 ro = *(const u32x8 GCRE_CONSTANT*)((const u32 GCRE_CONSTANT*)a.rec_slot + (u64)row0 * 8u);
+        const u32 ra = rc_a, rz = rc_z & 0x7fffffffu, rinfo = rc_info;
+        const u32x8 ro = rc_o;
         u32 yr[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) yr[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, ro[j], 0);
@@ -593,7 +628,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
         }
         const u32 rlen = rinfo & ~7u;
         if (rlen > 8u) {   // the producing join's list was long: the rest of it, 8 entries at a time
-          const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.rec_over + r_lov[row0]);
+          const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.rec_over + rc_lov);
           for (u32 p = 0u; p + 8u < rlen; p += 8u) {
             const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
             u32 yy[8], s4[4];
@@ -1135,6 +1170,39 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
 
 // general = true: the general kernel (both methods; method 1 then looks every count up -- the warm-up slice that seeds
 // the thresholds, and joins too small for pruning to pay)
+// Per segment of a launch whose paths0 rows come with a recipe: the recipe entries of the segment's row, gathered
+// next to the segment table (kRecSegWords words: paths0 row of the producing join, row it added, list info, where a
+// long list continues, the list's first 8 entries) so that the pruned kernel needs no load that depends on row0.
+__global__ __launch_bounds__(256) void k_fill_rec_segs(const SparseSeg* segs, i64 nsegs, const u32* r_row0, const u32* r_rowz,
+                                                       const u32* r_linfo, const u32* r_lover, const u32* r_slot, u32* out) {
+  const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 sidx = t >> 2;
+  const int part = (int)(t & 3);   // four threads per segment: the four scalars, then the slot in two halves
+  if (sidx >= nsegs) return;
+  const u32 row0 = segs[sidx].row0;
+  u32* o = out + sidx * kRecSegWords;
+  if (part == 0) {
+    o[0] = r_row0[row0];
+    o[1] = r_rowz[row0];
+  } else if (part == 1) {
+    o[2] = r_linfo[row0];
+    o[3] = r_lover[row0];
+  } else {
+    const u32x4 v = *(const u32x4*)(r_slot + (u64)row0 * 8u + (part - 2) * 4);
+    *(u32x4*)(o + 4 + (part - 2) * 4) = v;
+  }
+}
+
+hipError_t launch_fill_rec_segs(const SparseSeg* segs, int64_t nsegs, const uint32_t* r_row0, const uint32_t* r_rowz,
+                                const uint32_t* r_linfo, const uint32_t* r_lover, const uint32_t* r_slot, uint32_t* out,
+                                hipStream_t stream) {
+  if (nsegs == 0) return hipSuccess;
+  const i64 blocks = (nsegs * 4 + 255) / 256;
+  hipLaunchKernelGGL(k_fill_rec_segs, dim3((unsigned)blocks), dim3(256), 0, stream, segs, nsegs, r_row0, r_rowz, r_linfo, r_lover,
+                     r_slot, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general, hipStream_t stream) {
   const dim3 grid((unsigned)(8 * a.waves_per_xcd / kIeWaves));
   const dim3 block(64 * kIeWaves);

@@ -89,6 +89,7 @@ constexpr int kSparseSegMax = 64;
 hipError_t launch_null_sparse(const SparseArgs& a, int method, int planes, hipStream_t stream);
 int sparse_max_waves_per_cu(int method, int planes);   // resident waves per CU of the variant chosen for `planes` counter planes
 // ---- inclusion-exclusion null kernel on count planes (gcre_ie.hip) ----
+constexpr int kRecSegWords = 12;
 constexpr int kLadderLevels = 256;   // pruning thresholds j / kLadderPerUnit, j = 0 .. kLadderLevels-1
 constexpr int kLadderPerUnit = 8;
 constexpr int kLadder2Levels = 352;  // signed method: rows r <-> threshold r / (2 kLadderPerUnit), up to 4/3 of the method-1 range
@@ -130,6 +131,7 @@ struct IeArgs {
   int64_t nsegs;
   int64_t seg_begin, seg_end;        // slice of the segment table this launch walks
   uint32_t score_begin, score_end;   // joined paths of the launch outside [begin, end) only produce planes
+  const uint32_t* rec_segs;          // pruned method-1 kernel with a recipe: kRecSegWords words per segment (k_fill_rec_segs)
   int batch;                         // segments per ticket
   uint32_t* queue;                   // pruned kernels: the eight ticket counters of the launch (16 words apart), zero on entry
   uint32_t score_segs;               // the same range in segments: the table's first score_segs segments (they do not straddle)
@@ -139,6 +141,9 @@ struct IeArgs {
   int ladder_stride;         // = number of table diagonals
   uint32_t mt_rows, zoff;
 };
+hipError_t launch_fill_rec_segs(const SparseSeg* segs, int64_t nsegs, const uint32_t* r_row0, const uint32_t* r_rowz,
+                                const uint32_t* r_linfo, const uint32_t* r_lover, const uint32_t* r_slot, uint32_t* out,
+                                hipStream_t stream);
 hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general, hipStream_t stream);
 int ie_max_waves_per_cu(int method, int planes, int gz, bool out, bool rec);
 hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, const uint64_t* loff, const uint32_t* lidx,
