@@ -109,6 +109,7 @@ struct gcre_ctx {
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
   int ie_warm_segs = 2048;           // least number of segments in the warm-up slice (GCRE_IE_WARM)
+  int ie_small_join_tiles = 8;       // GCRE_IE_SJT (tuning)
   int ie_batch = 2;                  // segments per ticket (GCRE_IE_BATCH)
   uint32_t* d_queue = nullptr;       // ticket counters of the pruned kernels' work queues (8 x 16 words)
   uint32_t* d_max_tot = nullptr;     // 8 words: largest carrier total of the chunk, "reduced operand is wrong", overlap lists,
@@ -1191,9 +1192,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
           const int wpc = std::min(c->sparse_waves_per_cu, ie_max_waves_per_cu(g.method, planes, ia.gz, ia.planes_out != nullptr, ia.rec_slot != nullptr));
           ia.waves_per_xcd = std::max(4, (dev_cus * wpc / 8 / 4) * 4);
-          // small joins: a wave's fixed costs (cold TLB and caches, LDS set-up, threshold exchange) are per tile, so give
-          // every wave at least ~32 joined paths per tile
-          while (ia.waves_per_xcd > 4 && n < (int64_t)8 * ia.waves_per_xcd * 32)
+          // small joins: a wave's fixed costs (cold TLB and caches, LDS set-up, threshold exchange) are per tile it
+          // visits, so give every wave at least ~32 joined paths of a tile -- counting the tiles a queue can hold whole
+          // (a wave walks a contiguous piece of the tile-major sequence)
+          const int64_t ie_tile_factor = std::min(std::max(nkt_sp * c->ie_small_join_tiles / 8, 1), nkt_sp);
+          while (ia.waves_per_xcd > 4 && n * ie_tile_factor < (int64_t)8 * ia.waves_per_xcd * 32)
             ia.waves_per_xcd = std::max(4, (ia.waves_per_xcd / 2 / 4) * 4);
           c->prof.inspect_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
           {
@@ -1544,6 +1547,7 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
     c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : !std::strcmp(e, "ie") ? 3 : 0;
   if (const char* e = std::getenv("GCRE_IE_PRUNE")) c->ie_prune = std::atoi(e) != 0;
   if (const char* e = std::getenv("GCRE_IE_WARM")) c->ie_warm_segs = std::min(std::max(std::atoi(e), 1), 1 << 20);
+  if (const char* e = std::getenv("GCRE_IE_SJT")) c->ie_small_join_tiles = std::atoi(e);
   if (const char* e = std::getenv("GCRE_IE_BATCH")) c->ie_batch = std::min(std::max(std::atoi(e), 1), 4096);
   if (const char* e = std::getenv("GCRE_PLANES_OUT_MAX_MB")) c->planes_out_max = (size_t)std::max(0ll, std::atoll(e)) << 20;
   if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));
