@@ -193,6 +193,7 @@ struct gcre_uids {
   int64_t* d_location;
   int32_t* d_signs;
   std::vector<int64_t> h_path_idx;   // host copy, for building the sparse kernel's segment tables
+  mutable std::vector<int64_t> h_nonempty;   // prefix count of the uids with count > 0 (built on first use)
   std::vector<int64_t> h_location;   // host copy: segments are ordered by the paths1 rows they join (L2 reuse of their planes)
   struct SegCache { int64_t first, count, score_b, score_e, plane_b, plane_e; int64_t nsegs, nscored; SparseSeg* d_segs; };
   mutable std::vector<SegCache> seg_cache;
@@ -851,10 +852,14 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       const auto& pi = u.h_path_idx;
       int64_t lo = std::upper_bound(pi.begin(), pi.end(), first) - pi.begin() - 1;
       int64_t hi = std::lower_bound(pi.begin(), pi.end(), first + count) - pi.begin();   // first uid starting at/after the end
-      int64_t cnt = 0;
-      for (int64_t i = std::max<int64_t>(lo, 0); i < std::min(hi, u.n_uids); i++)
-        if (pi[(size_t)i + 1] > pi[(size_t)i]) cnt++;
-      return cnt;
+      if (u.h_nonempty.empty()) {   // prefix count of the uids that join anything: once per join index
+        u.h_nonempty.assign((size_t)u.n_uids + 1, 0);
+        for (int64_t i = 0; i < u.n_uids; i++)
+          u.h_nonempty[(size_t)i + 1] = u.h_nonempty[(size_t)i] + (pi[(size_t)i + 1] > pi[(size_t)i] ? 1 : 0);
+      }
+      lo = std::max<int64_t>(lo, 0);
+      hi = std::min(hi, u.n_uids);
+      return hi > lo ? u.h_nonempty[(size_t)hi] - u.h_nonempty[(size_t)lo] : (int64_t)0;
     };
     // compulsory HBM bytes of the permutation scoring of `count` joined paths: every paths0 row
     // once per uid, every paths1 row once per joined path, the masks and the maxima once, the join index
