@@ -945,16 +945,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         HIP_TRY(c, c->d_excess.reserve(ewords));
         HIP_TRY(c, hipMemsetAsync(c->d_excess.p, 0, ewords * 8, st));
         HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 32, st));
+        // its verdict lands in word 6 of the flag block, which the chunks leave alone: it is read with the first
+        // chunk's flags (no round trip of its own); a reduced row that is not even part of the row it stands for sends
+        // that chunk, and the join, back to paths1 itself like any other broken hint
         HIP_TRY(c, launch_range_union(jp.p1->d_rows, red->d_rows, u.d_red_index, u.d_pair_range, u.d_pair_loc, u.n_pairs, g.S,
-                                      g.Wp, g.method, c->d_excess.p, c->d_max_tot + 1, st));
-        uint32_t flag = 0;
-        HIP_TRY(c, hipMemcpyAsync(&flag, c->d_max_tot + 1, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        if (flag != 0) {   // the reduced rows are not even part of the rows they stand for: join on paths1 itself
-          hinted = false;
-          if (int rc = prepare_z()) return rc;
-          if (!have_pz) want_ie = false;
-        }
+                                      g.Wp, g.method, c->d_excess.p, c->d_max_tot + 6, st));
       }
       if (want_ie && keep) {
         // carriers of a joined row <= carriers(paths0 row) + carriers(added row); <= padded patient count
@@ -1044,7 +1039,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         if (use_sparse || use_ie) {
           collect_ie_stat();
           // flags of this chunk; the long-list counter (word 4) runs on across the chunks of a join that keeps a recipe
-          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, (rcp && recipe_started) ? 16 : 32, st));
+          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, (rcp && recipe_started) ? 16 : 24, st));   // words 6, 7: the join's
           recipe_started = recipe_started || rcp != nullptr;
           sa.max_tot = c->d_max_tot;
           HIP_TRY(c, c->d_dcnt.reserve((size_t)n * g.method));
@@ -1110,12 +1105,18 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           const uint64_t n_list = (uint64_t)nl * 8 + flags[4];
           const uint32_t max_tot = flags[0];
           join_max_tot = std::max(join_max_tot, max_tot);
-          if (flags[1] != 0) {
+          if (flags[1] != 0 || (hinted && flags[6] != 0)) {
             // the hint does not describe this join: run it on paths1 itself (identity map) from this chunk on
             if (!hinted) return fail(c, GCRE_ERR_DEVICE, "internal: joined path differs from paths0 | paths1");
             hinted = false;
             if (int rc = prepare_z()) return rc;
             if (!have_pz) want_ie = false;
+            // the kept rows' planes were sized for the reduced rows: rows of paths1 may carry more
+            if (res_planes && plane_groups_for(std::min<uint32_t>((uint32_t)(64 * g.Wp), row_max(c, jp.p0) + row_max(c, red))) >
+                                  jp.res->plane_groups) {
+              res_planes = false;
+              res_planes_ok = false;
+            }
             if (cb > sg.b || &sg != &segs.front()) recipe_broken = true;   // earlier chunks added rows of another set
             redo = true;
             break;

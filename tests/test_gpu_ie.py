@@ -83,6 +83,26 @@ def test_wrong_hint_is_detected_and_ignored(method, monkeypatch):
     ex.close()
 
 
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_wrong_hint_on_a_kept_level_changes_nothing(method, monkeypatch):
+    """A garbage reduced operand on level 2 -- a join that keeps its rows, their count planes and (unsigned method)
+    their recipe for level 3: detected on the device, the join runs on paths1 itself, the levels after it are built on
+    what it really produced."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_CHUNK_PATHS", "512")
+    p = sparse_problem(method, 23, K=140, L=4)
+    want = oracle.process_paths(p, order="canonical")
+    plan = api.ResidentPlan(p)
+    rng = np.random.default_rng(2)
+    n1 = plan.parsed[0].size
+    plan.uids["2"].set_reduced(plan.parsed[0], rng.integers(0, n1, len(p.levels.data_inds["3"])))
+    got = plan.run()
+    for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4)):
+        assert_same_result(got[name], want[f"lst{lvl}"])
+    np.testing.assert_array_equal(plan.kept["2"].to_numpy(), want["paths2"])
+    plan.close()
+
+
 def test_planes_are_rebuilt_when_the_masks_change(monkeypatch):
     """Count planes belong to one set of permutation masks: new masks on the same context, same path sets."""
     monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
