@@ -562,21 +562,25 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
 }
 
 // ---- top-k selection of one scored chunk: indices of the best min(k, valid) keys, ties cut in index order ----
-int select_chunk(gcre_ctx* c, int64_t first, int64_t count, int k, uint32_t* n_selected) {
-  *n_selected = 0;
+// Two halves, so that a caller with a read-back of its own (the inspector's flags) can fold the state's into it:
+// select_begin queues the eight digit passes (one read-back of the state they leave, gcre_kernels.hip) and the copy
+// of that state into *hs; select_finish -- after a stream synchronisation -- queues the collection of the winners.
+int select_begin(gcre_ctx* c, int64_t first, int64_t count, int k, SelectState* hs) {
+  *hs = SelectState{};
   if (count == 0 || k <= 0) return GCRE_OK;
   HIP_TRY(c, c->d_small.reserve(512));
   HIP_TRY(c, c->d_sel.reserve((size_t)k + 64));
-  uint32_t* d_hist = c->d_small.p;
+  SelectState* d_state = (SelectState*)(c->d_small.p + 264);
+  HIP_TRY(c, launch_radix_select(c->d_key.p + first, count, std::min<int64_t>(k, count), c->d_small.p, d_state, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hs, d_state, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
+  return GCRE_OK;
+}
+
+int select_finish(gcre_ctx* c, int64_t first, int64_t count, int k, const SelectState& hs, uint32_t* n_selected) {
+  *n_selected = 0;
+  if (count == 0 || k <= 0) return GCRE_OK;
   uint32_t* d_counter = c->d_small.p + 256;
   const uint64_t* key = c->d_key.p + first;   // selected indices are relative to `first`
-
-  // eight digit passes queued back to back; one read-back of the state they leave (gcre_kernels.hip)
-  SelectState* d_state = (SelectState*)(c->d_small.p + 264);
-  SelectState hs{};
-  HIP_TRY(c, launch_radix_select(key, count, std::min<int64_t>(k, count), d_hist, d_state, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(&hs, d_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
   const uint64_t prefix = hs.prefix;
   const int64_t need = hs.need, greater = hs.greater;
   const uint32_t eq_count = hs.eq_count;
@@ -613,6 +617,13 @@ int select_chunk(gcre_ctx* c, int64_t first, int64_t count, int k, uint32_t* n_s
   }
   *n_selected = nsel;
   return GCRE_OK;
+}
+
+int select_chunk(gcre_ctx* c, int64_t first, int64_t count, int k, uint32_t* n_selected) {
+  SelectState hs{};
+  if (int rc = select_begin(c, first, count, k, &hs)) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return select_finish(c, first, count, k, hs, n_selected);
 }
 
 struct JoinPlan {
@@ -986,6 +997,32 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       }
     }
     c->prof.prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
+    // top-k of a chunk: indices chosen by the radix select, their keys / counts / rows gathered and copied out
+    struct Winners {
+      std::vector<uint32_t> sel, cases, ctrls, r0, r1;
+      std::vector<uint64_t> key;
+      uint32_t n = 0;
+    };
+    auto queue_winners = [&](int64_t s0, uint32_t nsel, Winners& w) -> int {
+      w.n = nsel;
+      if (nsel == 0) return GCRE_OK;
+      HIP_TRY(c, c->d_wkey.reserve(nsel));
+      HIP_TRY(c, c->d_wcases.reserve(nsel));
+      HIP_TRY(c, c->d_wctrls.reserve(nsel));
+      HIP_TRY(c, c->d_wrow0.reserve(nsel));
+      HIP_TRY(c, c->d_wrow1.reserve(nsel));
+      HIP_TRY(c, launch_gather_winners(c->d_sel.p, nsel, c->d_key.p + s0, c->d_cases.p + s0, c->d_ctrls.p + s0,
+                                       c->d_row0.p + s0, c->d_row1.p + s0, c->d_wkey.p, c->d_wcases.p, c->d_wctrls.p, c->d_wrow0.p,
+                                       c->d_wrow1.p, st));
+      w.sel.resize(nsel); w.cases.resize(nsel); w.ctrls.resize(nsel); w.r0.resize(nsel); w.r1.resize(nsel); w.key.resize(nsel);
+      HIP_TRY(c, hipMemcpyAsync(w.sel.data(), c->d_sel.p, nsel * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(w.key.data(), c->d_wkey.p, nsel * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(w.cases.data(), c->d_wcases.p, nsel * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(w.ctrls.data(), c->d_wctrls.p, nsel * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(w.r0.data(), c->d_wrow0.p, nsel * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(w.r1.data(), c->d_wrow1.p, nsel * 4, hipMemcpyDeviceToHost, st));
+      return GCRE_OK;
+    };
     // only the inclusion-exclusion kernels score part of a chunk; every other form gets chunks cut at the shard's ends
     bool split = !(want_ie && g.K > 0);
     for (const Seg& sg : segs) {
@@ -1001,6 +1038,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         const int64_t s1 = std::max(s0, std::min(std::max<int64_t>(sg.se - cb, 0), n));
         const bool scored = s1 > s0;
         const bool partial = scored && (s0 > 0 || s1 < n);
+        SelectState sel_state{};
+        bool sel_begun = false, sel_done = false;
+        Winners win;
         const int64_t npt = (n + tile - 1) / tile;
         const int64_t padded = npt * tile;
         // the null kernel reads whole tiles: rows / totals beyond n must be valid (row 0, zero carriers)
@@ -1083,6 +1123,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         }
         HIP_TRY(c, hipEventRecord(e1, st));
         c->ev_stats.emplace_back(e0, e1);
+        // the top-k selection only needs the keys the inspector just wrote: its digit passes run now, their state
+        // comes back with the inspector's flags, its winners are collected before the null kernel starts
+        if (use_ie && g.K > 0 && scored) {
+          if (int rc = select_begin(c, s0, s1 - s0, c->top_k, &sel_state)) return rc;
+          sel_begun = true;
+        }
         if (!scored && !(use_ie && g.K > 0)) continue;
 
         bool ran_sparse = false, redo = false;
@@ -1221,6 +1267,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             if (!d_timing) HIP_TRY(c, hipMalloc((void**)&d_timing, 64));
             HIP_TRY(c, hipMemsetAsync(d_timing, 0, 64, st));
             ia.timing = d_timing;
+          }
+          if (sel_begun && scored) {
+            uint32_t nsel = 0;
+            if (int rc = select_finish(c, s0, s1 - s0, c->top_k, sel_state, &nsel)) return rc;
+            if (int rc = queue_winners(s0, nsel, win)) return rc;
+            sel_done = true;
           }
           hipEvent_t n0 = get_event(c), n1 = get_event(c);
           HIP_TRY(c, hipEventRecord(n0, st));
@@ -1390,30 +1442,17 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
 
         // ---- top-k of this chunk ----
         const auto ts0 = std::chrono::steady_clock::now();
-        uint32_t nsel = 0;
-        int rc = select_chunk(c, s0, s1 - s0, c->top_k, &nsel);
-        if (rc != GCRE_OK) return rc;
-        if (nsel > 0) {
-          HIP_TRY(c, c->d_wkey.reserve(nsel));
-          HIP_TRY(c, c->d_wcases.reserve(nsel));
-          HIP_TRY(c, c->d_wctrls.reserve(nsel));
-          HIP_TRY(c, c->d_wrow0.reserve(nsel));
-          HIP_TRY(c, c->d_wrow1.reserve(nsel));
-          HIP_TRY(c, launch_gather_winners(c->d_sel.p, nsel, c->d_key.p + s0, c->d_cases.p + s0, c->d_ctrls.p + s0,
-                                           c->d_row0.p + s0, c->d_row1.p + s0, c->d_wkey.p, c->d_wcases.p, c->d_wctrls.p, c->d_wrow0.p,
-                                           c->d_wrow1.p, st));
-          std::vector<uint32_t> h_sel(nsel), h_cases(nsel), h_ctrls(nsel), h_r0(nsel), h_r1(nsel);
-          std::vector<uint64_t> h_key(nsel);
-          HIP_TRY(c, hipMemcpyAsync(h_sel.data(), c->d_sel.p, nsel * 4, hipMemcpyDeviceToHost, st));
-          HIP_TRY(c, hipMemcpyAsync(h_key.data(), c->d_wkey.p, nsel * 8, hipMemcpyDeviceToHost, st));
-          HIP_TRY(c, hipMemcpyAsync(h_cases.data(), c->d_wcases.p, nsel * 4, hipMemcpyDeviceToHost, st));
-          HIP_TRY(c, hipMemcpyAsync(h_ctrls.data(), c->d_wctrls.p, nsel * 4, hipMemcpyDeviceToHost, st));
-          HIP_TRY(c, hipMemcpyAsync(h_r0.data(), c->d_wrow0.p, nsel * 4, hipMemcpyDeviceToHost, st));
-          HIP_TRY(c, hipMemcpyAsync(h_r1.data(), c->d_wrow1.p, nsel * 4, hipMemcpyDeviceToHost, st));
+        if (!sel_done) {
+          uint32_t nsel = 0;
+          int rc = select_chunk(c, s0, s1 - s0, c->top_k, &nsel);
+          if (rc != GCRE_OK) return rc;
+          if (int rc2 = queue_winners(s0, nsel, win)) return rc2;
+        }
+        if (win.n > 0) {
           HIP_TRY(c, hipStreamSynchronize(st));
-          for (uint32_t i = 0; i < nsel; i++)
-            cands.push_back(Candidate{key_to_score(h_key[i]), cb + s0 + (int64_t)h_sel[i], (int32_t)h_r0[i], (int32_t)h_r1[i],
-                                      (int32_t)h_cases[i], (int32_t)h_ctrls[i]});
+          for (uint32_t i = 0; i < win.n; i++)
+            cands.push_back(Candidate{key_to_score(win.key[i]), cb + s0 + (int64_t)win.sel[i], (int32_t)win.r0[i], (int32_t)win.r1[i],
+                                      (int32_t)win.cases[i], (int32_t)win.ctrls[i]});
         }
         select_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count();
         c->prof.paths += s1 - s0;
