@@ -1298,6 +1298,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (ia.seg_begin < ia.seg_end) {
             ia.queue = c->d_queue;
             ia.batch = c->ie_batch;
+            // tickets are 32-bit: (batches per tile) x tiles must stay below 2^32
+            while (((ia.nsegs - ia.seg_begin) / ia.batch + 1) * (int64_t)ia.nkt > (int64_t)0xf0000000ll) ia.batch *= 2;
             HIP_TRY(c, hipMemsetAsync(ia.queue, 0, 8 * 16 * 4, st));
             HIP_TRY(c, launch_null_ie(ia, g.method, planes, c->d_ladder == nullptr, st));
           }
