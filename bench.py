@@ -305,13 +305,13 @@ def main():
     ie = prof_acc.get("ie_launches", 0) > 0
     pmc = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_l_pmc.json" if ie else "r01_b_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_m_pmc.json" if ie else "r01_b_pmc_traffic.json")))
         same = pmc.get("workload") == args.config and not args.edges and not args.perms and not args.method and world == 1
         if same and (ie or row_loads > 0):
             roofline["traffic"] = pmc["traffic_bytes_per_null_launch"]
             roofline["traffic_source"] = ("profiles/%s (rocprofv3 FETCH_SIZE + WRITE_SIZE of the null kernels, raw KB x 1024; "
                                           "the count planes and lists, not in SURVEY's formula, are most of it)"
-                                          % ("r01_l_pmc.json" if ie else "r01_b_pmc_traffic.json"))
+                                          % ("r01_m_pmc.json" if ie else "r01_b_pmc_traffic.json"))
         else:
             pmc = pmc if ie else None
     except (OSError, ValueError, KeyError):
@@ -334,7 +334,7 @@ def main():
                             "see valu; `launches` counts joins (one warm-up + one pruned launch each)")
         roofline["valu"] = {"achieved": ach, "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
                             "instr_per_path_tile": per_tile,
-                            "source": "SQ_INSTS_VALU of the null kernels in profiles/r01_l_pmc.json / path-tiles of that run"}
+                            "source": "SQ_INSTS_VALU of the null kernels in profiles/r01_m_pmc.json / path-tiles of that run"}
     elif row_loads > 0:
         # sparse bit-sliced kernel: bound by the rate at which a CU pulls random 256-byte mask rows out of L2
         # (tools/row_gather_rate.hip measures ~40 G wave-loads/s on this chip), not by HBM and not by the VALU
