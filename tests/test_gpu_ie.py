@@ -284,6 +284,30 @@ def test_permutation_windows_change_nothing(method, tiles, monkeypatch):
         np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
 
 
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_windows_with_ranged_planes(method, monkeypatch):
+    """One-tile permutation windows and three ranks at path length 4: every window rebuilds the count planes of levels
+    1 and 2 for the rows the rank reads only (keep_ranged = 2), level 3 keeps a range of rows (keep_ranged = 1)."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_WINDOW_TILES", "1")
+    p = sparse_problem(method, 17, K=4500, L=4, genes=40, edges=110)
+    want = oracle.process_paths(p, order="canonical")
+    parts = []
+    for rank in range(3):
+        plan = api.ResidentPlan(p)
+        parts.append(plan.run(rank=rank, world=3))
+        assert plan.last_profile["ie_plane_joins"] == 5 * 3        # five joins, three windows, all on resident planes
+        plan.close()
+    for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4)):
+        null = np.maximum.reduce([r[name].null for r in parts])
+        rows = [np.stack([r[name].scores, r[name].src, r[name].trg, r[name].cases, r[name].ctrls], axis=1) for r in parts]
+        best = dist.merge_topk(np.vstack(rows), p.top_k)
+        w = want[f"lst{lvl}"]
+        assert len(null) == 4500
+        np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
+
+
 def test_perm_window_arguments():
     ex = api.JoinExec("method1", 40, 40, 5000)
     ex.set_perm_window(2048, 4096)
