@@ -16,6 +16,8 @@
 #include <limits>
 #include <string>
 #include <unordered_map>
+#include <thread>
+#include <functional>
 #include <vector>
 
 using namespace gcre;
@@ -500,51 +502,114 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
       return GCRE_OK;
     }
   HostTimer ht("sparse_segments");
-  std::vector<SparseSeg> segs, rest;
   const auto& pi = u.h_path_idx;
   const int64_t end = first + count;
-  // first uid whose range reaches past `first`
-  int64_t i = std::upper_bound(pi.begin(), pi.end(), first) - pi.begin() - 1;
-  for (; i < u.n_uids && pi[(size_t)i] < end; i++) {
-    const int64_t lo = std::max(pi[(size_t)i], first), hi = std::min(pi[(size_t)i + 1], end);
-    // the uid's paths before, inside and after the scored range
-    const int64_t cut[4] = {lo, std::min(std::max(score_b, lo), hi), std::min(std::max(score_e, lo), hi), hi};
-    for (int part = 0; part < 3; part++) {
-      std::vector<SparseSeg>& dst = (part == 1) ? segs : rest;
-      int64_t a0 = cut[part], a1 = cut[part + 1];
-      if (part != 1) {   // planes only: clip to the rows that want them
-        a0 = std::max(a0, plane_b);
-        a1 = std::min(a1, plane_e);
-      }
-      for (int64_t a = a0; a < a1; a += kSparseSegMax)
-        dst.push_back(SparseSeg{(uint32_t)i, (uint32_t)(a - first), (uint32_t)std::min<int64_t>(kSparseSegMax, a1 - a)});
-    }
+  // uids whose joined paths reach into [first, end)
+  const int64_t i_lo = std::max<int64_t>(0, (int64_t)(std::upper_bound(pi.begin(), pi.end(), first) - pi.begin()) - 1);
+  const int64_t i_hi = std::min<int64_t>(u.n_uids, (int64_t)(std::lower_bound(pi.begin(), pi.end(), end) - pi.begin()));
+  // Millions of uids: the table is built by a few host threads, each over a contiguous piece of the uid range with
+  // about the same number of joined paths (part 0: scored segments, part 1: the others; key = the paths1 row the uid
+  // joins first), and put together by a stable counting sort on the keys -- a noticeable part of a one-shot
+  // gcre_process_paths call when done by one thread with a comparison sort.
+  int T = 1;
+  if (i_hi - i_lo > 200000) T = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  struct Local {
+    std::vector<SparseSeg> part[2];
+    std::vector<uint32_t> key[2];
+    bool dense = true;
+    uint32_t max_key = 0;
+  };
+  std::vector<Local> loc((size_t)T);
+  std::vector<int64_t> cut((size_t)T + 1, i_hi);
+  cut[0] = i_lo;
+  for (int t = 1; t < T; t++) {
+    const int64_t want = first + count * t / T;
+    cut[(size_t)t] = std::min(i_hi, std::max(cut[(size_t)t - 1], (int64_t)(std::lower_bound(pi.begin() + i_lo, pi.begin() + i_hi, want) - pi.begin())));
   }
-  const size_t n_scored = segs.size();
+  auto build = [&](int t) {
+    Local& L = loc[(size_t)t];
+    const size_t guess = (size_t)(cut[(size_t)t + 1] - cut[(size_t)t]) + (size_t)(count / T / kSparseSegMax) + 16;
+    L.part[score_e > score_b ? 0 : 1].reserve(guess);
+    L.key[score_e > score_b ? 0 : 1].reserve(guess);
+    for (int64_t i = cut[(size_t)t]; i < cut[(size_t)t + 1]; i++) {
+      const int64_t lo = std::max(pi[(size_t)i], first), hi = std::min(pi[(size_t)i + 1], end);
+      if (hi <= lo) continue;
+      const int64_t l = u.h_location[(size_t)i];
+      if (l < 0 || l > 0xfffffff0ll) L.dense = false;
+      L.max_key = std::max(L.max_key, (uint32_t)l);
+      // the uid's paths before, inside and after the scored range
+      const int64_t pc[4] = {lo, std::min(std::max(score_b, lo), hi), std::min(std::max(score_e, lo), hi), hi};
+      for (int piece = 0; piece < 3; piece++) {
+        const int dst = (piece == 1) ? 0 : 1;
+        int64_t a0 = pc[piece], a1 = pc[piece + 1];
+        if (piece != 1) {   // planes only: clip to the rows that want them
+          a0 = std::max(a0, plane_b);
+          a1 = std::min(a1, plane_e);
+        }
+        for (int64_t a = a0; a < a1; a += kSparseSegMax) {
+          L.part[dst].push_back(SparseSeg{(uint32_t)i, (uint32_t)(a - first), (uint32_t)std::min<int64_t>(kSparseSegMax, a1 - a)});
+          L.key[dst].push_back((uint32_t)l);
+        }
+      }
+    }
+  };
+  auto run_all = [&](const std::function<void(int)>& fn) {
+    if (T == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(fn, t);
+    fn(0);
+    for (auto& x : th) x.join();
+  };
+  run_all(build);
+  size_t n_part[2] = {0, 0};
+  bool dense = true;
+  uint32_t max_key = 0;
+  for (const Local& L : loc) {
+    n_part[0] += L.part[0].size();
+    n_part[1] += L.part[1].size();
+    dense = dense && L.dense;
+    max_key = std::max(max_key, L.max_key);
+  }
+  const size_t n_scored = n_part[0];
   // Segments that join the same paths1 rows (all uids with the same pivot gene share `location`) run next to each
   // other: the waves of an XCD walk a contiguous window of this table, so the planes of those rows stay in its L2.
   // Any order gives the same maxima.
-  auto by_location = [&](std::vector<SparseSeg>& v) {
-    // a stable counting sort on `location` (rows of paths1: dense keys) -- a comparison sort of millions of
-    // segments is a noticeable part of a one-shot gcre_process_paths call
-    int64_t max_loc = 0;
-    for (const SparseSeg& sg : v) max_loc = std::max(max_loc, u.h_location[sg.row0]);
-    if (!v.empty() && max_loc < (int64_t)64 * (int64_t)v.size() + 1024) {
-      std::vector<uint32_t> start((size_t)max_loc + 2, 0);
-      for (const SparseSeg& sg : v) start[(size_t)u.h_location[sg.row0] + 1]++;
-      for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
-      std::vector<SparseSeg> sorted(v.size());
-      for (const SparseSeg& sg : v) sorted[start[(size_t)u.h_location[sg.row0]]++] = sg;
-      v.swap(sorted);
+  std::vector<SparseSeg> segs(n_part[0] + n_part[1]);
+  size_t base = 0;
+  for (int q = 0; q < 2; q++) {
+    const size_t nq = n_part[q];
+    if (nq == 0) continue;
+    const size_t nkeys = (size_t)max_key + 1;
+    if (dense && (uint64_t)nkeys * (uint64_t)T <= ((uint64_t)64 << 20) && (uint64_t)max_key < (uint64_t)64 * nq + 1024) {
+      // stable counting sort: per-thread histograms, then for every key the threads' slices one after the other
+      std::vector<std::vector<uint32_t>> start((size_t)T);
+      run_all([&](int t) {
+        start[(size_t)t].assign(nkeys, 0);
+        for (uint32_t k : loc[(size_t)t].key[q]) start[(size_t)t][k]++;
+      });
+      uint32_t run = 0;
+      for (size_t k = 0; k < nkeys; k++)
+        for (int t = 0; t < T; t++) {
+          const uint32_t h = start[(size_t)t][k];
+          start[(size_t)t][k] = run;
+          run += h;
+        }
+      run_all([&](int t) {
+        const Local& L = loc[(size_t)t];
+        std::vector<uint32_t>& st = start[(size_t)t];
+        for (size_t e = 0; e < L.part[q].size(); e++) segs[base + st[L.key[q][e]]++] = L.part[q][e];
+      });
     } else {
-      std::stable_sort(v.begin(), v.end(), [&](const SparseSeg& x, const SparseSeg& y) {
+      std::vector<SparseSeg> all;
+      all.reserve(nq);
+      for (const Local& L : loc) all.insert(all.end(), L.part[q].begin(), L.part[q].end());
+      std::stable_sort(all.begin(), all.end(), [&](const SparseSeg& x, const SparseSeg& y) {
         return u.h_location[x.row0] < u.h_location[y.row0];
       });
+      std::copy(all.begin(), all.end(), segs.begin() + (std::ptrdiff_t)base);
     }
-  };
-  by_location(segs);
-  by_location(rest);
-  segs.insert(segs.end(), rest.begin(), rest.end());
+    base += nq;
+  }
   SparseSeg* d = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d, std::max<size_t>(segs.size(), 1) * sizeof(SparseSeg)));
   if (!segs.empty())
@@ -704,25 +769,34 @@ int ensure_ranges(gcre_ctx* c, const gcre_uids& u) {
   std::vector<int32_t> range_of((size_t)std::max<int64_t>(u.n_uids, 1), 0);
   std::vector<int64_t> loc;
   std::vector<int32_t> cnt;
-  std::unordered_map<uint64_t, int32_t> seen;
-  seen.reserve((size_t)u.n_uids / 8 + 16);
+  // uids with the same pivot gene share (location, count): one slot per location remembers the first range seen
+  // there (direct-address table; a hash map when the locations are too spread out for one); a second count at the same
+  // location simply gets ranges of its own (sharing is an optimisation, correctness does not depend on it)
+  const bool direct = u.max_loc + 1 <= 8 * u.n_uids + ((int64_t)1 << 22);
+  std::vector<int32_t> by_loc(direct ? (size_t)std::max<int64_t>(u.max_loc + 1, 1) : 1, -1);
+  std::unordered_map<int64_t, int32_t> by_loc_map;
   for (int64_t i = 0; i < u.n_uids; i++) {
     const int64_t n = pi[(size_t)i + 1] - pi[(size_t)i];
     if (n <= 0) continue;   // never joined: its range is never looked at
-    const uint64_t key = ((uint64_t)u.h_location[(size_t)i] << 24) ^ (uint64_t)n;   // locations < 2^31, counts < 2^31
-    auto it = seen.find(key);
-    if (it == seen.end() || loc[(size_t)it->second] != u.h_location[(size_t)i] || cnt[(size_t)it->second] != (int32_t)n) {
-      if (it != seen.end()) {   // a collision of the mixed key: keep both, correctness does not depend on sharing
-        range_of[(size_t)i] = (int32_t)loc.size();
-        loc.push_back(u.h_location[(size_t)i]);
-        cnt.push_back((int32_t)n);
-        continue;
-      }
-      it = seen.emplace(key, (int32_t)loc.size()).first;
-      loc.push_back(u.h_location[(size_t)i]);
-      cnt.push_back((int32_t)n);
+    const int64_t l = u.h_location[(size_t)i];
+    int32_t r = -1;
+    if (direct) {
+      r = by_loc[(size_t)l];
+    } else {
+      auto it = by_loc_map.find(l);
+      if (it != by_loc_map.end()) r = it->second;
     }
-    range_of[(size_t)i] = it->second;
+    if (r < 0 || cnt[(size_t)r] != (int32_t)n) {
+      const int32_t fresh = (int32_t)loc.size();
+      loc.push_back(l);
+      cnt.push_back((int32_t)n);
+      if (r < 0) {
+        if (direct) by_loc[(size_t)l] = fresh;
+        else by_loc_map.emplace(l, fresh);
+      }
+      r = fresh;
+    }
+    range_of[(size_t)i] = r;
   }
   const size_t R = loc.size();
   std::vector<int32_t> pair_range;
