@@ -128,7 +128,7 @@ struct gcre_ctx {
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk, d_rec_segs;
   DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan, d_excess;
-  DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz, d_ie_scratch, d_linfo, d_lover, d_dover;
+  DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz, d_linfo, d_lover, d_dover;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
 
   // count-plane buffers of freed path sets, kept for the next set that needs one (hipMalloc of tens of GB costs
@@ -1325,16 +1325,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           while (ia.waves_per_xcd > 4 && n * ie_tile_factor < (int64_t)8 * ia.waves_per_xcd * 32)
             ia.waves_per_xcd = std::max(4, (ia.waves_per_xcd / 2 / 4) * 4);
           c->prof.inspect_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
-          {
-            // running maxima of the waves: 8 KB each, zero between launches (the kernel leaves them zero)
-            const size_t need = (size_t)8 * ia.waves_per_xcd * 2048;
-            if (need > c->d_ie_scratch.cap) {
-              HIP_TRY(c, c->d_ie_scratch.reserve(need));
-              HIP_TRY(c, hipMemsetAsync(c->d_ie_scratch.p, 0, need * 4, st));
-            }
-            ia.scratch = c->d_ie_scratch.p;
-            ia.stats = c->d_max_tot + 3;   // 4th word of the flag block: zeroed with it before k_stats ran
-          }
+          ia.stats = c->d_max_tot + 3;   // 4th word of the flag block: zeroed with it before k_stats ran
           static uint64_t* d_timing = nullptr;   // diagnostics builds only (-DGCRE_IE_TIMING), GCRE_IE_TIMING=1
           const bool timing = std::getenv("GCRE_IE_TIMING") != nullptr;
           if (timing) {
@@ -1714,7 +1705,6 @@ void gcre_destroy(gcre_ctx* c) {
   c->d_dcnt.release();
   c->d_dlist.release();
   c->d_rowz.release();
-  c->d_ie_scratch.release();
   c->d_linfo.release();
   c->d_lover.release();
   c->d_dover.release();

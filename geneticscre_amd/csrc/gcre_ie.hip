@@ -118,9 +118,12 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
   const i64 wx = a.waves_per_xcd;
   const i64 slices = 8 * wx;
   const u32 lane4 = (u32)lane * 4u;
-  // the wave's running maxima live in a private 8 KB strip of global memory (L2-resident), [q][lane]: they are only
-  // touched on the rare path that survives the pruning test
-  u32* scr = a.scratch + ((size_t)blockIdx.x * kIeWaves + wave) * 2048 + lane;
+  // the wave's 2048 running maxima of its current tile: 8 KB of LDS, [q][lane], flushed to the global array with
+  // atomicMax whenever the wave moves to another tile
+  __shared__ u32 gmax_lds[kIeWaves][32 * 64];
+  u32* scr = gmax_lds[wave] + lane;
+#pragma unroll
+  for (int q = 0; q < 32; q++) scr[q * 64] = 0u;
 
   const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
   const u64 GCRE_CONSTANT* loff0 = (const u64 GCRE_CONSTANT*)a.loff0;

@@ -125,7 +125,6 @@ struct IeArgs {
   uint32_t* null_bits;
   uint64_t* timing;          // diagnostics build (-DGCRE_IE_TIMING): 6 per-section cycle sums over all waves
   uint32_t* stats;           // optional: [0] += joined-path tiles that were looked up (not pruned)
-  uint32_t* scratch;         // 2048 dwords per wave of the launch, zero on entry and on exit: the waves' running maxima
   uint32_t* planes_out;      // optional: planes of the joined paths [tile][(out_first+q)*M+h][go][64][4]
   int64_t out_first;
   int64_t nsegs;
