@@ -413,9 +413,11 @@ size_t plane_bytes(const gcre_ctx* c, int64_t nrows, int groups) {
 }
 
 // room for `bytes` more on the device, leaving a quarter of what is free for the scratch of the join itself
-bool planes_fit(size_t bytes) {
+// `bytes` fit into three quarters of the free device memory (counting `reclaimable` bytes as free)
+bool planes_fit(size_t bytes, size_t reclaimable = 0) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  free_b += reclaimable;
   return bytes < free_b - free_b / 4;
 }
 
@@ -450,7 +452,11 @@ bool alloc_planes(gcre_ctx* c, const gcre_pathset* ps, int groups) {
     c->plane_pool.erase(c->plane_pool.begin() + best);
   } else {
     if (!planes_fit(bytes)) {
-      // make room: pooled buffers that are too small are of no use to anybody
+      // make room -- pooled buffers that are too small are of no use to this set -- but only when that helps: a set
+      // that cannot fit anyway (it will run on its recipe or on bit lists) must not cost the others their buffers
+      size_t pooled = 0;
+      for (const auto& pb : c->plane_pool) pooled += pb.bytes;
+      if (!planes_fit(bytes, pooled)) return false;
       for (auto& pb : c->plane_pool) (void)hipFree(pb.p);
       c->plane_pool.clear();
       if (!planes_fit(bytes)) return false;
