@@ -180,6 +180,8 @@ struct gcre_pathset {
   mutable uint64_t planes_epoch = 0;
   mutable bool planes_valid = false;
   mutable int64_t planes_lo = 0, planes_hi = 0;   // rows whose planes are valid (a multi-device join fills a range)
+  mutable bool planes_wanted = false;   // a later join had to rebuild this set's planes from its bit lists: next time the
+                                        // join that writes its rows leaves the planes too, whatever their size
 };
 
 // UidRelSet (src/gcre.h:49-90) resident on the device: prefix sums of count, locations, signs
@@ -1016,8 +1018,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           a_lo = ends[0];
           a_hi = (int64_t)ends[1] + 1;
         }
-        if (!planes_cover(c, rec_a, a_lo, a_hi))
+        if (!planes_cover(c, rec_a, a_lo, a_hi)) {
+          rec_a->planes_wanted = true;
           if (int rc = ensure_planes(c, rec_a)) return rc;
+        }
         if (int rc = ensure_planes(c, rec_z)) return rc;
         use_rec = planes_cover(c, rec_a, a_lo, a_hi) && planes_current(c, rec_z);
         have_p0 = use_rec;
@@ -1065,7 +1069,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             rcp->release();
             rcp = nullptr;
           } else {
-            want_out = plane_bytes(c, jp.res->nrows, out_groups) <= c->planes_out_max || use_rec;
+            want_out = plane_bytes(c, jp.res->nrows, out_groups) <= c->planes_out_max || use_rec || jp.res->planes_wanted;
           }
         }
         if (want_out) {
