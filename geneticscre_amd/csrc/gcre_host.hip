@@ -2300,6 +2300,9 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 2);
       if (!paths2) paths2 = new_pathset(c, total_paths(in->level[2]), true);
       PP_REQUIRE(paths2);
+      // the sequence is known here: when level 3's rows are too many to leave with count planes they leave with a recipe
+      // whose operand is this set -- which then must not be recipe-only itself (it would be rebuilt from bit lists)
+      if (L >= 4 && c->g.method == 1 && plane_bytes(c, total_paths(in->level[3]), 2) > c->planes_out_max) paths2->planes_wanted = true;
       // the reference reads data_idx2 from r_data_inds3 (wrapper.cpp:207); R passes identical vectors
       gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
       PP_REQUIRE(input);
