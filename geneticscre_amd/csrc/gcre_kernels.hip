@@ -396,29 +396,44 @@ hipError_t launch_masks_from_words(const uint64_t* packed, int nrows_in, const G
 // ------------------------------------------------------------------------------------------------
 // joined-path ordinal -> rows (the two nested loops of JoinExec::join, join_base.cpp:230-250)
 // ------------------------------------------------------------------------------------------------
+constexpr int kExpandRun = 8;   // consecutive joined paths per thread: one binary search, then a walk along the uids
+
 __global__ void k_expand(const i64* path_idx, const i64* location, i64 n_uids, const int32_t* signs, int path_length,
                          int method, i64 first, i64 count, u32* row0, u32* row1) {
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (i64)gridDim.x * blockDim.x) {
-    const i64 p = first + i;
+  const i64 runs = (count + kExpandRun - 1) / kExpandRun;
+  for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < runs; r += (i64)gridDim.x * blockDim.x) {
+    const i64 i0 = r * kExpandRun;
+    const i64 i1 = i0 + kExpandRun < count ? i0 + kExpandRun : count;
     // last uid whose first path ordinal is <= p (uids with count 0 share an ordinal with their successor)
     i64 lo = 0, hi = n_uids;   // invariant: path_idx[lo] <= p < path_idx[hi]
-    while (hi - lo > 1) {
-      const i64 mid = (lo + hi) >> 1;
-      if (path_idx[mid] <= p) lo = mid; else hi = mid;
+    {
+      const i64 p = first + i0;
+      while (hi - lo > 1) {
+        const i64 mid = (lo + hi) >> 1;
+        if (path_idx[mid] <= p) lo = mid; else hi = mid;
+      }
     }
-    const i64 idx = lo;
-    const i64 loc = location[idx] + (p - path_idx[idx]);
-    u32 swap = 0;
-    if (method == 2) {
-      // UidRelSet::need_flip (gcre.h:71-81): sign == 1 keeps path1's halves, otherwise they swap
-      int sign;
-      if (path_length > 3) sign = signs[idx];
-      else if (path_length < 3) sign = signs[loc];
-      else sign = (signs[idx] + signs[loc] == 0) ? -1 : 1;
-      swap = (sign == 1) ? 0u : 1u;
+    i64 idx = lo;
+    i64 next = path_idx[idx + 1];   // first ordinal of the uid after idx
+    for (i64 i = i0; i < i1; i++) {
+      const i64 p = first + i;
+      while (next <= p) {           // the same "last uid with path_idx <= p" as the search: empty uids are stepped over
+        idx++;
+        next = path_idx[idx + 1];
+      }
+      const i64 loc = location[idx] + (p - path_idx[idx]);
+      u32 swap = 0;
+      if (method == 2) {
+        // UidRelSet::need_flip (gcre.h:71-81): sign == 1 keeps path1's halves, otherwise they swap
+        int sign;
+        if (path_length > 3) sign = signs[idx];
+        else if (path_length < 3) sign = signs[loc];
+        else sign = (signs[idx] + signs[loc] == 0) ? -1 : 1;
+        swap = (sign == 1) ? 0u : 1u;
+      }
+      row0[i] = (u32)idx;
+      row1[i] = (u32)loc | (swap << 31);
     }
-    row0[i] = (u32)idx;
-    row1[i] = (u32)loc | (swap << 31);
   }
 }
 
