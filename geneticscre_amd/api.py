@@ -44,7 +44,8 @@ class gcre_profile(ctypes.Structure):
                 ("paths", ctypes.c_int64), ("scores", ctypes.c_int64), ("null_alg_bytes", ctypes.c_double),
                 ("null_row_loads", ctypes.c_double), ("ie_launches", ctypes.c_int64),
                 ("ie_overlap_lists", ctypes.c_int64), ("ie_hinted_joins", ctypes.c_int64),
-                ("ie_plane_joins", ctypes.c_int64), ("ie_lookup_tiles", ctypes.c_int64), ("prepare_ms", ctypes.c_double), ("inspect_ms", ctypes.c_double)]
+                ("ie_plane_joins", ctypes.c_int64), ("ie_lookup_tiles", ctypes.c_int64), ("prepare_ms", ctypes.c_double), ("inspect_ms", ctypes.c_double),
+                ("ie_quad_launches", ctypes.c_int64)]
 
 
 class gcre_level(ctypes.Structure):

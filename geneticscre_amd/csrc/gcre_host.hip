@@ -110,6 +110,8 @@ struct gcre_ctx {
   double* d_dmax = nullptr;          // method 2 null table (vtmax)
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
+  uint32_t* d_mtq = nullptr;         // the same rows with their dwords in the quad kernel's lane order (gcre_ieq.hip)
+  int ie_quad = 1;                   // GCRE_IE_QUAD=0: the pruned method-1 launches stay on k_null_ie_m1 (cross-check)
   int ie_warm_segs = 2048;           // least number of segments in the warm-up slice (GCRE_IE_WARM)
   int ie_small_join_tiles = 8;       // GCRE_IE_SJT (tuning)
   int ie_batch = 2;                  // segments per ticket (GCRE_IE_BATCH)
@@ -153,6 +155,7 @@ struct gcre_recipe {
   uint64_t a_id = 0, z_id = 0;     // the operands: path-set ids and the versions of their rows
   uint64_t a_ver = 0, z_ver = 0;
   DevBuf<uint32_t> row0, rowz, linfo, lover, slot, over;
+  uint32_t max_len = 0;            // longest list (padded) the producing join's inspector wrote
   bool valid = false;
   void release() {
     for (auto* b : {&row0, &rowz, &linfo, &lover, &slot, &over}) b->release();
@@ -199,7 +202,16 @@ struct gcre_uids {
   std::vector<int64_t> h_path_idx;   // host copy, for building the sparse kernel's segment tables
   mutable std::vector<int64_t> h_nonempty;   // prefix count of the uids with count > 0 (built on first use)
   std::vector<int64_t> h_location;   // host copy: segments are ordered by the paths1 rows they join (L2 reuse of their planes)
-  struct SegCache { int64_t first, count, score_b, score_e, plane_b, plane_e; int64_t nsegs, nscored; SparseSeg* d_segs; };
+  struct SegCache {
+    int64_t first, count, score_b, score_e, plane_b, plane_e;
+    int64_t nsegs, nscored;
+    SparseSeg* d_segs;
+    // quad table of the pruned method-1 kernel (gcre_ieq.hip), built on first use for one warm-up length: runs of up to
+    // four consecutive segments that join the same paths1 rows, none straddling `q_warm` or `nscored`
+    std::vector<SparseSeg> h_segs;
+    int64_t q_warm = -1, nquads = 0, quad_begin = 0;
+    uint32_t* d_quads = nullptr;
+  };
   mutable std::vector<SegCache> seg_cache;
   // optional hint (gcre_uids_set_reduced): paths0[idx] | paths1[loc] == paths0[idx] | red[red_index[loc]] for every
   // joined path; checked on the device for every join, ignored when it does not hold
@@ -311,7 +323,11 @@ int build_transposed_masks(gcre_ctx* c) {
   const size_t bytes = (size_t)nkt * mt_rows * 64 * 4;
   if (!c->d_mt) HIP_TRY(c, hipMalloc((void**)&c->d_mt, bytes));
   HIP_TRY(c, hipMemsetAsync(c->d_mt, 0, bytes, c->stream));
-  HIP_TRY(c, launch_build_mt(c->d_masks, 2 * g.Wp, g.Kpad, nkt, mt_rows, c->d_mt, c->stream));
+  if (g.method == 1 && c->ie_quad) {
+    if (!c->d_mtq) HIP_TRY(c, hipMalloc((void**)&c->d_mtq, bytes));
+    HIP_TRY(c, hipMemsetAsync(c->d_mtq, 0, bytes, c->stream));
+  }
+  HIP_TRY(c, launch_build_mt(c->d_masks, 2 * g.Wp, g.Kpad, nkt, mt_rows, c->d_mt, c->d_mtq, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->mask_epoch++;   // every count plane built so far belongs to the old masks
   c->win_k0 = 0;
@@ -498,15 +514,17 @@ int ensure_planes(gcre_ctx* c, const gcre_pathset* ps) {
 // (*nscored of them); of the others only the paths inside [plane_b, plane_e) are listed (the rest need no count
 // planes).  Cached per uids object (the join index is resident input; repeated joins reuse it).
 int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t count, int64_t score_b, int64_t score_e,
-                    int64_t plane_b, int64_t plane_e, const SparseSeg** d_out, int64_t* nsegs, int64_t* nscored) {
+                    int64_t plane_b, int64_t plane_e, const SparseSeg** d_out, int64_t* nsegs, int64_t* nscored,
+                    gcre_uids::SegCache** entry = nullptr) {
   plane_b = std::max(plane_b, first);
   plane_e = std::min(plane_e, first + count);
-  for (const auto& sc : u.seg_cache)
+  for (auto& sc : u.seg_cache)
     if (sc.first == first && sc.count == count && sc.score_b == score_b && sc.score_e == score_e && sc.plane_b == plane_b &&
         sc.plane_e == plane_e) {
       *d_out = sc.d_segs;
       *nsegs = sc.nsegs;
       *nscored = sc.nscored;
+      if (entry) *entry = &sc;
       return GCRE_OK;
     }
   HostTimer ht("sparse_segments");
@@ -516,8 +534,9 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
   const int64_t i_lo = std::max<int64_t>(0, (int64_t)(std::upper_bound(pi.begin(), pi.end(), first) - pi.begin()) - 1);
   const int64_t i_hi = std::min<int64_t>(u.n_uids, (int64_t)(std::lower_bound(pi.begin(), pi.end(), end) - pi.begin()));
   // Millions of uids: the table is built by a few host threads, each over a contiguous piece of the uid range with
-  // about the same number of joined paths (part 0: scored segments, part 1: the others; key = the paths1 row the uid
-  // joins first), and put together by a stable counting sort on the keys -- a noticeable part of a one-shot
+  // about the same number of joined paths (part 0: scored segments, part 1: the others; key = the paths1 row the SEGMENT
+  // joins first: all uids with one pivot gene join the same rows, so equal keys = the same added rows, which is what the
+  // quad kernel shares), and put together by a stable counting sort on the keys -- a noticeable part of a one-shot
   // gcre_process_paths call when done by one thread with a comparison sort.
   int T = 1;
   if (i_hi - i_lo > 200000) T = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
@@ -556,7 +575,10 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
         }
         for (int64_t a = a0; a < a1; a += kSparseSegMax) {
           L.part[dst].push_back(SparseSeg{(uint32_t)i, (uint32_t)(a - first), (uint32_t)std::min<int64_t>(kSparseSegMax, a1 - a)});
-          L.key[dst].push_back((uint32_t)l);
+          const int64_t k = l + (a - pi[(size_t)i]);
+          if (k > 0xfffffff0ll) L.dense = false;
+          L.key[dst].push_back((uint32_t)k);
+          L.max_key = std::max(L.max_key, (uint32_t)k);
         }
       }
     }
@@ -611,9 +633,8 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
       std::vector<SparseSeg> all;
       all.reserve(nq);
       for (const Local& L : loc) all.insert(all.end(), L.part[q].begin(), L.part[q].end());
-      std::stable_sort(all.begin(), all.end(), [&](const SparseSeg& x, const SparseSeg& y) {
-        return u.h_location[x.row0] < u.h_location[y.row0];
-      });
+      auto key_of = [&](const SparseSeg& x) { return u.h_location[x.row0] + ((int64_t)x.first + first - pi[x.row0]); };
+      std::stable_sort(all.begin(), all.end(), [&](const SparseSeg& x, const SparseSeg& y) { return key_of(x) < key_of(y); });
       std::copy(all.begin(), all.end(), segs.begin() + (std::ptrdiff_t)base);
     }
     base += nq;
@@ -625,12 +646,51 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
   HIP_TRY(c, hipStreamSynchronize(c->stream));   // segs is a local
   if (u.seg_cache.size() >= 64) {                // bound the cache: drop the oldest table
     (void)hipFree(u.seg_cache.front().d_segs);
+    if (u.seg_cache.front().d_quads) (void)hipFree(u.seg_cache.front().d_quads);
     u.seg_cache.erase(u.seg_cache.begin());
   }
   u.seg_cache.push_back({first, count, score_b, score_e, plane_b, plane_e, (int64_t)segs.size(), (int64_t)n_scored, d});
+  if (c->g.method == 1 && c->ie_quad) u.seg_cache.back().h_segs = std::move(segs);
+  if (entry) *entry = &u.seg_cache.back();
   *d_out = d;
-  *nsegs = (int64_t)segs.size();
+  *nsegs = u.seg_cache.back().nsegs;
   *nscored = (int64_t)n_scored;
+  return GCRE_OK;
+}
+
+// Quad table of a cached segment table (see gcre_ieq.hip): greedy runs of up to four consecutive segments with the same
+// first joined paths1 row and the same length -- they join the same rows --, cut at `n_warm` (the pruned launch starts
+// there) and at the end of the scored segments.  quad_begin = the first quad of the pruned launch.
+int ensure_quads(gcre_ctx* c, const gcre_uids& u, gcre_uids::SegCache& sc, int64_t n_warm) {
+  if (sc.q_warm == n_warm && sc.d_quads) return GCRE_OK;
+  HostTimer ht("ensure_quads");
+  const auto& pi = u.h_path_idx;
+  const int64_t n = (int64_t)sc.h_segs.size();
+  if (n != sc.nsegs || n >= ((int64_t)1 << 30)) return GCRE_ERR_ARG;   // no host copy (or too many segments): the caller falls back
+  std::vector<uint32_t> quads;
+  quads.reserve((size_t)n / 3 + 16);
+  int64_t quad_begin = -1;
+  auto key_of = [&](const SparseSeg& x) { return u.h_location[x.row0] + ((int64_t)x.first + sc.first - pi[x.row0]); };
+  int64_t i = 0;
+  while (i < n) {
+    if (i >= n_warm && quad_begin < 0) quad_begin = (int64_t)quads.size();
+    const int64_t stop = i < n_warm ? n_warm : (i < sc.nscored ? sc.nscored : n);
+    const int64_t k0 = key_of(sc.h_segs[(size_t)i]);
+    const uint32_t n0 = sc.h_segs[(size_t)i].n;
+    int64_t j = i + 1;
+    while (j < stop && j < i + 4 && sc.h_segs[(size_t)j].n == n0 && key_of(sc.h_segs[(size_t)j]) == k0) j++;
+    quads.push_back((uint32_t)i | ((uint32_t)(j - i - 1) << 30));
+    i = j;
+  }
+  if (quad_begin < 0) quad_begin = (int64_t)quads.size();
+  if (sc.d_quads) (void)hipFree(sc.d_quads);
+  sc.d_quads = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&sc.d_quads, std::max<size_t>(quads.size(), 1) * 4));
+  if (!quads.empty()) HIP_TRY(c, hipMemcpyAsync(sc.d_quads, quads.data(), quads.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // quads is a local
+  sc.q_warm = n_warm;
+  sc.nquads = (int64_t)quads.size();
+  sc.quad_begin = quad_begin;
   return GCRE_OK;
 }
 
@@ -718,8 +778,10 @@ void free_uids(gcre_uids* u) {
   for (void* p : {(void*)u->d_path_idx, (void*)u->d_location, (void*)u->d_signs, (void*)u->d_red_index,
                   (void*)u->d_range_of, (void*)u->d_pair_range, (void*)u->d_pair_loc})
     if (p) (void)hipFree(p);
-  for (auto& sc : u->seg_cache)
+  for (auto& sc : u->seg_cache) {
     if (sc.d_segs) (void)hipFree(sc.d_segs);
+    if (sc.d_quads) (void)hipFree(sc.d_quads);
+  }
   delete u;
 }
 
@@ -973,7 +1035,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     bool have_pz = false, have_p0 = false, res_planes = false, res_planes_ok = false, use_rec = false;
     const gcre_pathset *rec_a = nullptr, *rec_z = nullptr;
     gcre_recipe* rcp = nullptr;   // the recipe this join leaves with the rows it keeps (method 1)
-    uint32_t join_max_tot = 0;
+    uint32_t join_max_tot = 0, join_max_len = 0;
     bool ie_ran = false, ie_stat_pending = false, recipe_started = false, recipe_broken = false;
     auto collect_ie_stat = [&]() {
       if (!ie_stat_pending) return;
@@ -1183,6 +1245,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sa.range_of = hinted ? u.d_range_of : nullptr;
           sa.bad = c->d_max_tot + 1;
           sa.ie_bias = 8;
+          sa.ie_rule = (g.method == 1 && c->ie_quad) ? 1 : 0;
           if (rcp) {   // straight into the recipe of the kept set (absolute row = cb + i)
             sa.rowz = rcp->rowz.p + cb;
             sa.linfo = rcp->linfo.p + cb;
@@ -1235,6 +1298,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           const uint64_t n_list = (uint64_t)nl * 8 + flags[4];
           const uint32_t max_tot = flags[0];
           join_max_tot = std::max(join_max_tot, max_tot);
+          join_max_len = std::max(join_max_len, flags[5]);
           if (flags[1] != 0 || (hinted && flags[6] != 0)) {
             // the hint does not describe this join: run it on paths1 itself (identity map) from this chunk on
             if (!hinted) return fail(c, GCRE_ERR_DEVICE, "internal: joined path differs from paths0 | paths1");
@@ -1268,8 +1332,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           while (planes < 16 && (max_tot >> planes) != 0) planes++;
           IeArgs ia{};
           int64_t nseg_scored = 0;
+          gcre_uids::SegCache* seg_entry = nullptr;
           if (int rc = sparse_segments(c, u, cb, n, cb + s0, cb + s1, res_planes ? pl_b : cb + s0, res_planes ? pl_e : cb + s1,
-                                       &ia.segs, &ia.nsegs, &nseg_scored))
+                                       &ia.segs, &ia.nsegs, &nseg_scored, &seg_entry))
             return rc;
           ia.mt = w_mt;
           ia.tot = c->d_tot.p;
@@ -1360,8 +1425,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             // shard gives it an eighth of its segments, not all of them.
             // every tile warms up on its own permutations: with many tiles the slice gets shorter (its cost is per tile)
             const int64_t warm_min = std::max<int64_t>(256, (int64_t)c->ie_warm_segs * 8 / std::max(nkt_sp, 8));
-            const int64_t n_warm = std::min<int64_t>(nseg_scored, std::min<int64_t>(std::max<int64_t>(warm_min, nseg_scored / 1024),
-                                                                                    std::max<int64_t>(256, nseg_scored / 8)));
+            int64_t n_warm = std::min<int64_t>(nseg_scored, std::min<int64_t>(std::max<int64_t>(warm_min, nseg_scored / 1024),
+                                                                              std::max<int64_t>(256, nseg_scored / 8)));
+            if (c->ie_warm_segs == 0) n_warm = 0;   // GCRE_IE_WARM=0 (tests): everything through the pruned kernel, thresholds from 0
             IeArgs wa = ia;
             wa.seg_end = n_warm;
             // a wave walks its tiles one after the other: keep enough waves that each gets about four (segment, tile) items
@@ -1373,10 +1439,33 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (ia.seg_begin < ia.seg_end) {
             ia.queue = c->d_queue;
             ia.batch = c->ie_batch;
+            // method 1: the quad form (gcre_ieq.hip) wherever segments come in groups that join the same paths1 rows --
+            // every level but the one whose uids are the genes themselves (one uid per pivot)
+            bool quad = false;
+            // (it sums lists of up to 56 entries in registers: longer ones, here or in the recipe, keep the launch on k_null_ie_m1)
+            const bool short_lists = flags[5] <= 56u && (!use_rec || jp.p0->rec->max_len <= 56u);
+            if (g.method == 1 && c->d_ladder && c->ie_quad && c->d_mtq && short_lists && seg_entry &&
+                ensure_quads(c, u, *seg_entry, ia.seg_begin) == GCRE_OK) {
+              const int64_t nq = seg_entry->nquads - seg_entry->quad_begin;
+              quad = nq > 0 && ((ia.seg_end - ia.seg_begin) * 2 >= nq * 5 || c->ie_quad == 2);   // 2.5 segments per quad on average
+              if (quad) {
+                ia.mtq = c->d_mtq + (size_t)(c->win_k0 / kSparseTile) * (size_t)(64 * g.Wp + 1) * 64;
+                ia.quads = seg_entry->d_quads;
+                ia.quad_begin = seg_entry->quad_begin;
+                ia.quad_end = seg_entry->nquads;
+                ia.batch = std::max(1, c->ie_batch / 2);   // a quad is up to four segments
+                const int wq = std::min(c->sparse_waves_per_cu, ieq_max_waves_per_cu(planes, ia.gz, ia.planes_out != nullptr, ia.rec_slot != nullptr));
+                ia.waves_per_xcd = std::max(4, (dev_cus * wq / 8 / 4) * 4);
+                while (ia.waves_per_xcd > 4 && n * ie_tile_factor < (int64_t)8 * ia.waves_per_xcd * 128)
+                  ia.waves_per_xcd = std::max(4, (ia.waves_per_xcd / 2 / 4) * 4);
+              }
+            }
             // tickets are 32-bit: (batches per tile) x tiles must stay below 2^32
             while (((ia.nsegs - ia.seg_begin) / ia.batch + 1) * (int64_t)ia.nkt > (int64_t)0xf0000000ll) ia.batch *= 2;
             HIP_TRY(c, hipMemsetAsync(ia.queue, 0, 8 * 16 * 4, st));
-            HIP_TRY(c, launch_null_ie(ia, g.method, planes, c->d_ladder == nullptr, st));
+            if (quad) HIP_TRY(c, launch_null_ie_quad(ia, planes, st));
+            else HIP_TRY(c, launch_null_ie(ia, g.method, planes, c->d_ladder == nullptr, st));
+            if (quad) c->prof.ie_quad_launches++;
           }
           HIP_TRY(c, hipEventRecord(n1, st));
           if (timing) {
@@ -1543,6 +1632,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       rcp->z_id = red->id;
       rcp->z_ver = red->version;
       rcp->valid = true;
+      rcp->max_len = join_max_len;
       jp.res->max_bits = (join_max_tot + 3u) & ~3u;
       jp.res->max_known = true;
     }
@@ -1668,9 +1758,10 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   if (const char* e = std::getenv("GCRE_NULL_KERNEL"))
     c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : !std::strcmp(e, "ie") ? 3 : 0;
   if (const char* e = std::getenv("GCRE_IE_PRUNE")) c->ie_prune = std::atoi(e) != 0;
-  if (const char* e = std::getenv("GCRE_IE_WARM")) c->ie_warm_segs = std::min(std::max(std::atoi(e), 1), 1 << 20);
+  if (const char* e = std::getenv("GCRE_IE_WARM")) c->ie_warm_segs = std::min(std::max(std::atoi(e), 0), 1 << 20);
   if (const char* e = std::getenv("GCRE_IE_SJT")) c->ie_small_join_tiles = std::atoi(e);
   if (const char* e = std::getenv("GCRE_IE_BATCH")) c->ie_batch = std::min(std::max(std::atoi(e), 1), 4096);
+  if (const char* e = std::getenv("GCRE_IE_QUAD")) c->ie_quad = std::min(std::max(std::atoi(e), 0), 2);   // 2: wherever it can run
   if (const char* e = std::getenv("GCRE_PLANES_OUT_MAX_MB")) c->planes_out_max = (size_t)std::max(0ll, std::atoll(e)) << 20;
   if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));
 
@@ -1702,7 +1793,7 @@ void gcre_destroy(gcre_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void* p : {(void*)c->d_case_mask, (void*)c->d_masks, (void*)c->d_t32, (void*)c->d_dvt, (void*)c->d_dmax,
-                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot, (void*)c->d_queue, (void*)c->d_ladder})
+                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_mtq, (void*)c->d_max_tot, (void*)c->d_queue, (void*)c->d_ladder})
     if (p) (void)hipFree(p);
   for (auto* b : {&c->d_row0, &c->d_row1, &c->d_tot, &c->d_cases, &c->d_ctrls, &c->d_sel, &c->d_small, &c->d_chunk,
                   &c->d_rec_segs, &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})

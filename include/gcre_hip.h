@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GCRE_ABI_VERSION 2
+#define GCRE_ABI_VERSION 3
 
 typedef enum {
   GCRE_OK = 0,
@@ -83,6 +83,7 @@ typedef struct {
   int64_t ie_lookup_tiles;    /* joined-path x 2048-permutation tiles that survived the pruning test (method 1) */
   double prepare_ms;          /* host wall time: bit lists / count planes of the operands (once per set and mask epoch) */
   double inspect_ms;          /* host wall time: list offsets (scan), list fill and the syncs around them */
+  int64_t ie_quad_launches;   /* of ie_launches: pruned method-1 launches that ran the four-paths-per-wave form (gcre_ieq.hip) */
 } gcre_profile;
 
 /* ---- context: JoinExec::JoinExec, src/join_base.cpp:37-59.  method 1 = unsigned, 2 = signed. ---- */

@@ -27,6 +27,12 @@ def set_kernel(monkeypatch, kernel):
     if kernel == "ie-noprune":
         monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
         monkeypatch.setenv("GCRE_IE_PRUNE", "0")
+    elif kernel in ("ie-quad", "ie-m1"):
+        # the pruned method-1 launches in their four-paths-per-wave form (gcre_ieq.hip) wherever it can run, or never;
+        # no warm-up slice, so that small joins reach the pruned kernels at all
+        monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+        monkeypatch.setenv("GCRE_IE_QUAD", "2" if kernel == "ie-quad" else "0")
+        monkeypatch.setenv("GCRE_IE_WARM", "0")
     else:
         monkeypatch.setenv("GCRE_NULL_KERNEL", kernel)
 
@@ -48,7 +54,7 @@ def test_appendix_b_golden(case):
             assert (s, (a, b)) in ids
 
 
-@pytest.mark.parametrize("kernel", ["auto", "ie", "ie-noprune", "sparse", "dense"])
+@pytest.mark.parametrize("kernel", ["auto", "ie", "ie-quad", "ie-m1", "ie-noprune", "sparse", "dense"])
 @pytest.mark.parametrize("method", ["method1", "method2"])
 @pytest.mark.parametrize("n_perm", [0, 3, 100, 130, 700])
 def test_process_paths_matches_oracle(method, n_perm, kernel, monkeypatch):
@@ -71,7 +77,7 @@ def test_wide_masks_and_hypergeometric_table(method):
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
 
 
-@pytest.mark.parametrize("kernel", ["auto", "ie", "ie-noprune", "sparse", "dense"])
+@pytest.mark.parametrize("kernel", ["auto", "ie", "ie-quad", "ie-m1", "ie-noprune", "sparse", "dense"])
 @pytest.mark.parametrize("method,n_perm", [("method1", 1100), ("method2", 600), ("method1", 2500)])
 def test_baseline_mask_width_full_parity(method, n_perm, kernel, monkeypatch):
     """BASELINE configs[2] geometry (5,000 patients = 79 mask words, real -log hypergeometric table, K not a
@@ -131,7 +137,7 @@ from helpers import fnv_rows, load_ref_cases  # noqa: E402
 REF_CASES = load_ref_cases()
 
 
-@pytest.mark.parametrize("kernel", ["auto", "ie", "ie-noprune", "sparse", "dense"])
+@pytest.mark.parametrize("kernel", ["auto", "ie", "ie-quad", "ie-m1", "ie-noprune", "sparse", "dense"])
 @pytest.mark.parametrize("name,p,exp", REF_CASES, ids=[c[0] for c in REF_CASES])
 def test_hip_matches_reference_scoring_code(name, p, exp, kernel, monkeypatch):
     """The HIP path against goldens printed by the reference's own scoring code (oracle/ref_partial): score values,
