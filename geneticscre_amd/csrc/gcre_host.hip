@@ -1245,7 +1245,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sa.range_of = hinted ? u.d_range_of : nullptr;
           sa.bad = c->d_max_tot + 1;
           sa.ie_bias = 8;
-          sa.ie_rule = (g.method == 1 && c->ie_quad) ? 1 : 0;
+          sa.ie_rule = g.method == 1 ? 1 : 0;   // the bound filter and the quad kernel want overlap lists
           if (rcp) {   // straight into the recipe of the kept set (absolute row = cb + i)
             sa.rowz = rcp->rowz.p + cb;
             sa.linfo = rcp->linfo.p + cb;
@@ -1415,6 +1415,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             sel_done = true;
           }
           hipEvent_t n0 = get_event(c), n1 = get_event(c);
+          bool ie_quad_ran = false;
           HIP_TRY(c, hipEventRecord(n0, st));
           ia.seg_begin = 0;
           ia.seg_end = ia.nsegs;
@@ -1466,6 +1467,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             if (quad) HIP_TRY(c, launch_null_ie_quad(ia, planes, st));
             else HIP_TRY(c, launch_null_ie(ia, g.method, planes, c->d_ladder == nullptr, st));
             if (quad) c->prof.ie_quad_launches++;
+            ie_quad_ran = quad;
           }
           HIP_TRY(c, hipEventRecord(n1, st));
           if (timing) {
@@ -1473,6 +1475,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             HIP_TRY(c, hipMemcpyAsync(tmv, d_timing, 64, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
             const double waves = 8.0 * ia.waves_per_xcd;
+            if (ie_quad_ran)
+              std::fprintf(stderr, "[ieq timing] paths %lld waves %.0f iterations/wave %.0f: per-wave Mcycles head %.2f sums %.2f long %.2f fetch %.2f counts(incl lookups) %.2f lookups %.2f total %.2f\n",
+                           (long long)n, waves, tmv[7] / waves, tmv[0] / waves / 1e6, tmv[1] / waves / 1e6, tmv[2] / waves / 1e6, tmv[3] / waves / 1e6,
+                           tmv[4] / waves / 1e6, tmv[5] / waves / 1e6, tmv[6] / waves / 1e6);
+            else
             std::fprintf(stderr, "[ie timing] paths %lld out %d waves %.0f: per-wave Mcycles seg %.2f load %.2f comp(incl load) %.2f lookup %.2f exch %.2f total %.2f, slowest wave %.2f\n",
                          (long long)n, ia.planes_out != nullptr, waves, tmv[0] / waves / 1e6, tmv[1] / waves / 1e6,
                          tmv[2] / waves / 1e6, tmv[3] / waves / 1e6, tmv[4] / waves / 1e6, tmv[5] / waves / 1e6, tmv[6] / 1e6);

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
           load_planes(ZR, a.rec_planes_z, (u32)(((u64)kt * (u64)a.rec_rows_z + rz) * (u64)a.rec_gz), a.rec_gz);
 #pragma unroll
           for (int l = 0; l < L; l++) S[l] = 0u;
-          const u32 rlen = rinfo & ~7u;
+          const u32 rlen = rinfo & kLinfoLenMask;
           stream(S, (const u32 GCRE_CONSTANT*)(a.rec_slot + (u64)row0 * 8u), 0, 8);
           if (rlen > 8u) stream(S, (const u32 GCRE_CONSTANT*)(a.rec_over + a.rec_lover[row0]), 0, (u64)(rlen - 8u));
           u32 cy = 0u, bw = 0u;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
 #pragma unroll
         for (int h = 0; h < M; h++) {
           const u32 r0 = rdlane(infov[h], t);
-          const u32 len = r0 & ~7u;
+          const u32 len = r0 & kLinfoLenMask;
           const bool overlap = (r0 & 1u) != 0u;
           // the 8 mask rows every list starts with (zero rows past its real end) ...
           u32 offs[8], y[8];
@@ -486,9 +486,13 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
       // the first 8 entries of every list (lists are padded to 8: most lists end there) are wave-uniform: they come
       // through the scalar cache, one s_load_dwordx8 per path, fetched one path ahead of the loads that use them
       const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 8u);
+      // OUT (every count is needed): the path's 8 mask rows and the added row's planes.  Otherwise only the planes: the
+      // rows are fetched by the lanes the bound filter leaves uncertain (see compute)
       auto issue = [&](u32 t2, const u32x8 offs, u32 (&yy)[8], u32 (&ZZ)[4 * GZ]) {
+        if constexpr (OUT) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+          for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+        }
         const u32x4* src = (const u32x4*)(a.planesz + (u64)rdlane(zunit, t2) * 256u) + lane;
 #pragma unroll
         for (int j = 0; j < GZ; j++) {
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
           for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
         }
-        const u32 rlen = rinfo & ~7u;
+        const u32 rlen = rinfo & kLinfoLenMask;
         if (rlen > 8u) {   // the producing join's list was long: the rest of it, 8 entries at a time
           const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.rec_over + rc_lov);
           for (u32 p = 0u; p + 8u < rlen; p += 8u) {
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
       auto compute = [&](u32 t, const u32 (&y)[8], const u32 (&Z)[4 * GZ]) {
         GCRE_TM_MARK(tp0);
         const u32 r0 = rdlane(infov, t);
-        const u32 len = r0 & ~7u;
+        const u32 len = r0 & kLinfoLenMask;
         const bool overlap = (r0 & 1u) != 0u;
         u32 C[L];
         u32 S4[4];
@@ -719,14 +723,156 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
         GCRE_TM_ADD(3, tp3, tp2);
       };
 
-      for (u32 t = 0; t < npaths; t += 2) {
-        issue(at(t + 1), oB, yB, ZB);
-        oA = slots[at(t + 2)];
-        compute(t, yA, ZA);
-        if (t + 1 < npaths) {
-          issue(at(t + 2), oA, yA, ZA);
-          oB = slots[at(t + 3)];
-          compute(t + 1, yB, ZB);
+      // ---- !OUT: the bound filter.  count = W - S with W = B + Nz known from the planes alone and 0 <= S <= ov, the
+      // length of the path's overlap list.  A permutation with lo + ov <= W <= hi has its count inside [lo, hi] whatever
+      // its S is: it cannot raise a maximum, and its 8 mask rows need not be read.  Only the lanes that hold a permutation
+      // outside that narrower interval fetch the rows (exec-masked loads), finish the count and test it exactly; what
+      // still falls outside [lo, hi] is looked up as before.  ~3/4 of the path-tiles end after 2 plane loads and ~45 bit
+      // instructions.  (Delta lists -- rare since the inspector prefers overlap lists -- skip the filter.)
+      auto compute_f = [&](u32 t, const u32x8 o, const u32 (&Z)[4 * GZ]) {
+        const u32 r0 = rdlane(infov, t);
+        const u32 len = r0 & kLinfoLenMask;
+        const bool overlap = (r0 & 1u) != 0u;
+        const u32 ov = len - (r0 >> 28);          // the list's true length
+        const u32 lh = rdlane(lhv, t);
+        const u32 lo = lh & 0xffffu, hi = lh >> 16;
+        u32 W[L];
+        u32 mu = valid;
+        if (overlap) {
+          u32 cy = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            if (l < 4 * GZ) {
+              W[l] = xor3(B[l], Z[l < 4 * GZ ? l : 0], cy);
+              cy = majority(B[l], Z[l < 4 * GZ ? l : 0], cy);
+            } else {
+              W[l] = B[l] ^ cy;
+              cy = B[l] & cy;
+            }
+          }
+          u32 lo2 = lo ? lo + ov : 0u;            // counts are never negative: lo = 0 needs no margin
+          lo2 = lo2 > 0xffffu ? 0xffffu : lo2;
+          u32 blo = 0u, bhi = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            const u32 kl = (u32)__builtin_amdgcn_sbfe((int)lo2, l, 1);
+            const u32 kh = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
+            blo = borrow3(W[l], kl, blo);    // W < lo + ov
+            bhi = borrow3(kh, W[l], bhi);    // W > hi
+          }
+          if ((lo2 >> L) != 0u) blo = 0xffffffffu;   // the margin pushed the bound past the counters' range
+          mu = (blo | bhi) & valid;
+        } else {
+#pragma unroll
+          for (int l = 0; l < L; l++) W[l] = B[l];
+        }
+        if (__builtin_amdgcn_ballot_w64(mu != 0u) == 0ull) return;
+        u32 slow = 0u;
+        if (mu != 0u) {
+          // ---- the uncertain lanes: rows, exact count, exact test ----
+          u32 y[8], S4[4];
+#pragma unroll
+          for (int j = 0; j < 8; j++) y[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o[j], 0);
+          sum8(y, S4);
+          u32 S[L];
+#pragma unroll
+          for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
+          if (len > 8u) {   // long list: further blocks of 8 entries
+            const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + rdlane(lovv, t));
+            for (u32 p = 0u; p + 8u < len; p += 8u) {
+              const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
+              u32 yy[8], s4[4];
+#pragma unroll
+              for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o8[j], 0);
+              sum8(yy, s4);
+              u32 cy = 0u;
+#pragma unroll
+              for (int l = 0; l < L; l++) {
+                const u32 sv = S[l];
+                if (l < 4) {
+                  S[l] = xor3(sv, s4[l < 4 ? l : 0], cy);
+                  cy = majority(sv, s4[l < 4 ? l : 0], cy);
+                } else {
+                  S[l] = sv ^ cy;
+                  cy = sv & cy;
+                }
+              }
+            }
+          }
+          u32 C[L];
+          if (overlap) {   // C = W - S
+            u32 bw = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              C[l] = xor3(W[l], S[l], bw);
+              bw = borrow3(W[l], S[l], bw);
+            }
+          } else {         // C = B + S
+            u32 cy = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              C[l] = xor3(W[l], S[l], cy);
+              cy = majority(W[l], S[l], cy);
+            }
+          }
+          u32 blo = 0u, bhi = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            const u32 kl = (u32)__builtin_amdgcn_sbfe((int)lo, l, 1);
+            const u32 kh = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
+            blo = borrow3(C[l], kl, blo);
+            bhi = borrow3(kh, C[l], bhi);
+          }
+          u32 m = (blo | bhi) & mu;
+          if (m != 0u) {
+            slow = 1u;
+            const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(rdlane(totv, t));
+            while (m != 0u) {
+              u32 bb[4], vv[4];
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                bb[k] = m ? (u32)__builtin_ctz(m) : bb[k ? k - 1 : 0];
+                m &= m - 1u;
+                u32 cnt = 0u;
+#pragma unroll
+                for (int l = 0; l < L; l++) cnt |= ((C[l] >> bb[k]) & 1u) << l;
+                vv[k] = diag_g[cnt];
+              }
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                __hip_atomic_fetch_max(nm + bb[k] * 64, vv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_max_u32
+            }
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(slow != 0u) != 0ull) {
+          n_slow++;
+          dirty = true;
+        }
+      };
+
+      if constexpr (OUT) {
+        for (u32 t = 0; t < npaths; t += 2) {
+          issue(at(t + 1), oB, yB, ZB);
+          oA = slots[at(t + 2)];
+          compute(t, yA, ZA);
+          if (t + 1 < npaths) {
+            issue(at(t + 2), oA, yA, ZA);
+            oB = slots[at(t + 3)];
+            compute(t + 1, yB, ZB);
+          }
+        }
+      } else {
+        // the planes of path t+1 are in flight while path t is tested; the list entries stay in scalar registers until
+        // their path has been tested
+        for (u32 t = 0; t < npaths; t += 2) {
+          issue(at(t + 1), oB, yB, ZB);
+          compute_f(t, oA, ZA);
+          if (t + 1 < npaths) {
+            oA = slots[at(t + 2)];
+            issue(at(t + 2), oA, yA, ZA);
+            compute_f(t + 1, oB, ZB);
+            oB = slots[at(t + 3)];
+          }
         }
       }
     }
@@ -926,7 +1072,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
       u32 C[2][L];
       auto compute = [&](int h, u32 t, const u32 (&y)[8], const u32 (&Z)[LZ]) {
         const u32 r0 = rdlane(infov[h], t);
-        const u32 len = r0 & ~7u;
+        const u32 len = r0 & kLinfoLenMask;
         const bool overlap = (r0 & 1u) != 0u;
         u32 S[L];
         {
@@ -1583,7 +1729,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((M == 1 && 
         else if (ov_ok) over[p - 8u] = a.zoff;
       }
       if (active && sl == 0) {
-        a.linfo[d] = len8 | mode[h];
+        a.linfo[d] = len8 | mode[h] | ((len8 - len[h]) << 28);
         a.lover[d] = ovb;
         my_max_len = max(my_max_len, len8);
       }

@@ -36,6 +36,15 @@ typedef u32 __attribute__((ext_vector_type(3))) u32x3;
 // (a & m) | (b & ~m)
 __device__ __forceinline__ u32 mux3(u32 a, u32 b, u32 m) { return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4); }
 
+// -DGCRE_IE_TIMING: per-section s_memtime sums (no extra waits: a mark only reads the clock)
+#ifdef GCRE_IE_TIMING
+#define GCRE_QT(var) const u64 var = __builtin_amdgcn_s_memtime()
+#define GCRE_QT_ADD(i, t1, t0) tm[i] += (t1) - (t0)
+#else
+#define GCRE_QT(var)
+#define GCRE_QT_ADD(i, t1, t0)
+#endif
+
 template <int L, int GZ, bool OUT, bool REC>
 __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2))) void k_null_ie_q(const IeArgs a) {
   constexpr int LP = (L + 3) / 4 * 4;
@@ -65,11 +74,15 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
 
   int cur_kt = -1;
   u32 valid = 0u;          // exchange(): lane = dword `lane` of the tile
-  u32 validd[4] = {0u, 0u, 0u, 0u};   // the path loop: dwords sub + 16 d
+  bool tail_tile = false;  // the tile holds fewer than 2048 live permutations
   u32 lad_base = (k_lad_mode == 0u) ? 0u : ((u32)kLadderLevels - 1u + k_lad_mode) * k_lstride;
   const u32 lad_keep = (u32)kLadderLevels * k_lstride;
   bool dirty = false;
   u32 n_slow = 0u;
+#ifdef GCRE_IE_TIMING
+  u64 tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // quad header + base counters, row sums (incl. the wait for the rows), long lists, fetch, counts + test, look-ups, total, iterations
+  const u64 tm_begin = __builtin_amdgcn_s_memtime();
+#endif
   __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)k_mtq, 0, 0x7fffffff, 0x00020000);
   const u32 sub16 = (u32)sub * 16u;
 
@@ -135,17 +148,14 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
       mt = __builtin_amdgcn_make_buffer_rsrc((void*)(k_mtq + (size_t)kt * k_mt_rows * 64), 0, 0x7fffffff, 0x00020000);
       const int live = (int)k_K - kt * 2048 - lane * 32;
       valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        const int lv = (int)k_K - kt * 2048 - (sub + 16 * d) * 32;
-        validd[d] = lv >= 32 ? 0xffffffffu : (lv <= 0 ? 0u : ((1u << lv) - 1u));
-      }
+      tail_tile = (int)k_K - kt * 2048 < 2048;
       if (k_lad_mode == 0u) lad_base = 0u;
       since = 0;
       period = 1;
     }
     for (u32 qi = q_lo; qi < q_hi; qi++) {
       // ---- the quad: up to four consecutive segments that join the same paths1 rows; spare groups shadow the last one
+      GCRE_QT(tq0);
       const u32 qe = a.quads[qi];
       const u32 qcnt = (qe >> 30) + 1u;
       const u32 sidx = (qe & 0x3fffffffu) + ((u32)grp < qcnt ? (u32)grp : qcnt - 1u);
@@ -205,30 +215,29 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
         for (int jz = 0; jz < GZ; jz++) zz[jz] = zsrc[jz * 64];
         pm.lh = a.ladder[lad_row + pm.tot];
         pm.e2a = pm.e2b = u32x4{a.zoff, a.zoff, a.zoff, a.zoff};
-        if (__builtin_amdgcn_ballot_w64((pm.info & ~7u) > 8u) != 0ull) {   // somebody's list goes on (lists start 32-byte aligned)
-          const u32x4* more = (const u32x4*)(a.dover + ((pm.info & ~7u) > 8u ? pm.lov : 0u));
+        if (__builtin_amdgcn_ballot_w64((pm.info & kLinfoLenMask) > 8u) != 0ull) {   // somebody's list goes on (lists start 32-byte aligned)
+          const u32x4* more = (const u32x4*)(a.dover + ((pm.info & kLinfoLenMask) > 8u ? pm.lov : 0u));
           const u32x4 ma = more[0], mb = more[1];
-          if ((pm.info & ~7u) > 8u) { pm.e2a = ma; pm.e2b = mb; }
+          if ((pm.info & kLinfoLenMask) > 8u) { pm.e2a = ma; pm.e2b = mb; }
         }
       };
       // the rest of a list: 8 more rows per round, every round summed into the planes S; groups that are through add the
-      // all-zero row.  `first_block` = entries already fetched (block 1) or nullptr: fetch them like the others
-      auto add_blocks = [&](u32 (&S)[kQS][4], u32 len, u32 maxlen, const u32* over, u32 lov, const u32x4* e2a, const u32x4* e2b) {
+      // all-zero row.  y2 = the rows of entries 8..15, already requested by the caller (or nullptr: fetch them here)
+      auto add_blocks = [&](u32 (&S)[kQS][4], u32 len, u32 maxlen, const u32* over, u32 lov, const u32x4 (*y2p)[8]) {
         for (u32 q = 8u; q < maxlen; q += 8u) {
-          u32 o8[8];
-          if (q == 8u && e2a) {
-            o8[0] = e2a->x; o8[1] = e2a->y; o8[2] = e2a->z; o8[3] = e2a->w;
-            o8[4] = e2b->x; o8[5] = e2b->y; o8[6] = e2b->z; o8[7] = e2b->w;
+          u32x4 y2[8];
+          if (q == 8u && y2p) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) y2[k] = (*y2p)[k];
           } else {
             const u32x4* more = (const u32x4*)(over + (q < len ? lov + q - 8u : 0u));
             const u32x4 ma = more[0], mb = more[1];
             const bool in = q < len;
-            o8[0] = in ? ma.x : a.zoff; o8[1] = in ? ma.y : a.zoff; o8[2] = in ? ma.z : a.zoff; o8[3] = in ? ma.w : a.zoff;
-            o8[4] = in ? mb.x : a.zoff; o8[5] = in ? mb.y : a.zoff; o8[6] = in ? mb.z : a.zoff; o8[7] = in ? mb.w : a.zoff;
-          }
-          u32x4 y2[8];
+            const u32 o8[8] = {in ? ma.x : a.zoff, in ? ma.y : a.zoff, in ? ma.z : a.zoff, in ? ma.w : a.zoff,
+                               in ? mb.x : a.zoff, in ? mb.y : a.zoff, in ? mb.z : a.zoff, in ? mb.w : a.zoff};
 #pragma unroll
-          for (int k = 0; k < 8; k++) y2[k] = __builtin_amdgcn_raw_buffer_load_b128(mt, o8[k] + sub16, 0, 0);
+            for (int k = 0; k < 8; k++) y2[k] = __builtin_amdgcn_raw_buffer_load_b128(mt, o8[k] + sub16, 0, 0);
+          }
 #pragma unroll
           for (int d = 0; d < 4; d++) {
             u32 r8[8], s4[4];
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
         load_groups(A, a.rec_planes_a, ((u64)kt * (u64)a.rec_rows_a + (u64)ra) * (u64)a.rec_ga, a.rec_ga);
         load_groups(ZR, a.rec_planes_z, ((u64)kt * (u64)a.rec_rows_z + (u64)rz) * (u64)a.rec_gz, a.rec_gz);
         const u32 mo = (rinfo & 1u) ? 0xffffffffu : 0u;   // the producing join's list: overlap (A + Z - S) or delta (A + S)
-        const u32 rlen = rinfo & ~7u;
+        const u32 rlen = rinfo & kLinfoLenMask;
         u32 S[kQS][4];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
           for (int l = 0; l < kQS; l++) S[l][d] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
         }
         if (__builtin_amdgcn_ballot_w64(rlen > 8u) != 0ull)   // rare: a long list in the recipe
-          add_blocks(S, rlen, __builtin_amdgcn_readfirstlane(wave_max_u32(rlen)), a.rec_over, rlov, nullptr, nullptr);
+          add_blocks(S, rlen, __builtin_amdgcn_readfirstlane(wave_max_u32(rlen)), a.rec_over, rlov, nullptr);
         // T = X - Y with (X, Y) = (Z, S) for an overlap list, (S, 0) for a delta list; B = A + T
 #pragma unroll
         for (int d = 0; d < 4; d++) {
@@ -320,23 +329,30 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
       PathMeta pm;
       u32x4 y[8], zg[GZ];
       fetch(0u, pm, y, zg);
-      u32 Mn[kQMeta];   // the next chunk's metadata on its way (segments longer than 16 paths)
-      bool have_mn = false;
 
       // ---- one joined path per group and iteration.  The rows are summed first (they leave their registers), then the
       // next path's loads go out, then the counts are put together and tested: one set of row buffers.
+      GCRE_QT(tq1);
+      GCRE_QT_ADD(0, tq1, tq0);
       for (u32 j = 0; j < npaths; j++) {
-        if ((j & (kQChunk - 1)) == 0u && j + kQChunk < npaths) {
-          stage_load(j + kQChunk, Mn);
-          have_mn = true;
-        }
+        GCRE_QT(ti0);
         // the added row's planes to LDS: lane l holds dword l of GZ plane groups; lane (g, s) reads dwords s + 16 d
 #pragma unroll
         for (int jz = 0; jz < GZ; jz++) zst[jz * 64 + lane] = zg[jz];
         const u32 info = pm.info, tot = pm.tot, lh = pm.lh;
-        const u32 len = info & ~7u;
+        const u32 len = info & kLinfoLenMask;
         const u32 mo = (info & 1u) ? 0xffffffffu : 0u;
         const bool all_overlap = __builtin_amdgcn_ballot_w64((info & 1u) == 0u) == 0ull;
+        // 10-20 % of the paths: some group's list is longer than its slot.  The rows of its entries 8..15 (the entries came
+        // with the path's other loads) go out before the slot's rows are summed
+        const bool any_long = __builtin_amdgcn_ballot_w64(len > 8u) != 0ull;
+        u32x4 y2[8];
+        if (any_long) {
+          const u32 o8[8] = {pm.e2a.x, pm.e2a.y, pm.e2a.z, pm.e2a.w, pm.e2b.x, pm.e2b.y, pm.e2b.z, pm.e2b.w};
+#pragma unroll
+          for (int k = 0; k < 8; k++) y2[k] = __builtin_amdgcn_raw_buffer_load_b128(mt, o8[k] + sub16, 0, 0);
+        }
+        const u32 lov = pm.lov;
         u32 S[kQS][4];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
@@ -347,16 +363,21 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
           for (int l = 0; l < kQS; l++) S[l][d] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
         }
-        if (__builtin_amdgcn_ballot_w64(len > 8u) != 0ull) {   // 10-20 % of the paths: the list is longer than its slot
-          const u32x4 e2a = pm.e2a, e2b = pm.e2b;
-          add_blocks(S, len, __builtin_amdgcn_readfirstlane(wave_max_u32(len)), a.dover, pm.lov, &e2a, &e2b);
-        }
-        // ---- the next path's loads; at a chunk boundary its metadata has to be in LDS first ----
-        if (((j + 1u) & (kQChunk - 1)) == 0u && have_mn) {
+        GCRE_QT(ti1);
+        GCRE_QT_ADD(1, ti1, ti0);
+        if (any_long) add_blocks(S, len, __builtin_amdgcn_readfirstlane(wave_max_u32(len)), a.dover, lov, &y2);
+        GCRE_QT(ti2);
+        GCRE_QT_ADD(2, ti2, ti1);
+        // ---- the next path's loads; at a chunk boundary the next 16 paths' metadata has to be in LDS first (the row
+        // buffers are free at this point: the staging registers cost nothing; one exposed round trip per 16 paths)
+        if (((j + 1u) & (kQChunk - 1)) == 0u && j + 1u < npaths) {
+          u32 Mn[kQMeta];
+          stage_load(j + 1u, Mn);
           stage_store(Mn);
-          have_mn = false;
         }
         fetch(j + 1u, pm, y, zg);
+        GCRE_QT(ti3);
+        GCRE_QT_ADD(3, ti3, ti2);
 
         const u32 lo = lh & 0xffffu, hi = lh >> 16;
         u32 kl[L], kh[L];
@@ -366,13 +387,17 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
           kh[l] = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
         }
         u32 any_m = 0u;
+        u32x4 zn[GZ];   // the added row's planes of dwords sub + 16 d, read from LDS one d ahead
+#pragma unroll
+        for (int jz = 0; jz < GZ; jz++) zn[jz] = zst[jz * 64 + sub];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
           u32 Z[LZ];
 #pragma unroll
           for (int jz = 0; jz < GZ; jz++) {
-            const u32x4 v = zst[jz * 64 + sub + 16 * d];
+            const u32x4 v = zn[jz];
             Z[4 * jz + 0] = v.x; Z[4 * jz + 1] = v.y; Z[4 * jz + 2] = v.z; Z[4 * jz + 3] = v.w;
+            if (d < 3) zn[jz] = zst[jz * 64 + sub + 16 * (d + 1)];
           }
           u32 C[L];
           if (all_overlap) {
@@ -435,9 +460,14 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
             blo = borrow3(C[l], kl[l], blo);    // C - lo borrows  <=>  C < lo
             bhi = borrow3(kh[l], C[l], bhi);    // hi - C borrows  <=>  C > hi
           }
-          u32 m = (blo | bhi) & validd[d];
+          u32 m = blo | bhi;
+          if (tail_tile) {   // dwords sub + 16 d of the last tile: permutations past K do not exist
+            const int lv = (int)k_K - kt * 2048 - (sub + 16 * d) * 32;
+            m &= lv >= 32 ? 0xffffffffu : (lv <= 0 ? 0u : ((1u << lv) - 1u));
+          }
           if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
           // ---- the few permutations that can raise a maximum: rebuild each count from the planes, look it up ----
+          GCRE_QT(tl0);
           any_m |= m;
           const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(tot);
           u32* nmw = nmax_lds[wave] + (sub + 16 * d);
@@ -457,7 +487,14 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
               __hip_atomic_fetch_max(nmw + bb[k] * 64, vv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_max_u32
           }
           dirty = true;
+          GCRE_QT(tl1);
+          GCRE_QT_ADD(5, tl1, tl0);
         }
+        GCRE_QT(ti4);
+        GCRE_QT_ADD(4, ti4, ti3);
+#ifdef GCRE_IE_TIMING
+        tm[7] += 1;
+#endif
         if (a.stats) {   // joined paths (of the up to four) with at least one look-up in this tile
           const unsigned long long bal = __builtin_amdgcn_ballot_w64(any_m != 0u);
           if (bal) {
@@ -470,6 +507,11 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
     }
   }
   flush_tile();
+#ifdef GCRE_IE_TIMING
+  tm[6] = __builtin_amdgcn_s_memtime() - tm_begin;
+  if (a.timing && lane == 0)
+    for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)a.timing + i, (unsigned long long)tm[i]);
+#endif
   if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
 }
 

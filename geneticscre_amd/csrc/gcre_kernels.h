@@ -90,6 +90,9 @@ hipError_t launch_null_sparse(const SparseArgs& a, int method, int planes, hipSt
 int sparse_max_waves_per_cu(int method, int planes);   // resident waves per CU of the variant chosen for `planes` counter planes
 // ---- inclusion-exclusion null kernel on count planes (gcre_ie.hip) ----
 constexpr int kRecSegWords = 12;
+// linfo word of a list: padded length (multiple of 8, >= 8) | mode (bit 0: 1 = overlap list) | (padding entries) << 28,
+// so that the list's true length = padded length - padding is known without walking it (the bound filter of k_null_ie_m1)
+constexpr uint32_t kLinfoLenMask = 0x0ffffff8u;
 constexpr int kLadderLevels = 256;   // pruning thresholds j / kLadderPerUnit, j = 0 .. kLadderLevels-1
 constexpr int kLadderPerUnit = 8;
 constexpr int kLadder2Levels = 352;  // signed method: rows r <-> threshold r / (2 kLadderPerUnit), up to 4/3 of the method-1 range
