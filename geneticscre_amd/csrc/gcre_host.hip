@@ -110,7 +110,6 @@ struct gcre_ctx {
   double* d_dmax = nullptr;          // method 2 null table (vtmax)
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
-  uint32_t* d_mtq = nullptr;         // the same rows with their dwords in the quad kernel's lane order (gcre_ieq.hip)
   int ie_quad = 1;                   // GCRE_IE_QUAD=0: the pruned method-1 launches stay on k_null_ie_m1 (cross-check)
   int ie_warm_segs = 2048;           // least number of segments in the warm-up slice (GCRE_IE_WARM)
   int ie_small_join_tiles = 8;       // GCRE_IE_SJT (tuning)
@@ -323,11 +322,7 @@ int build_transposed_masks(gcre_ctx* c) {
   const size_t bytes = (size_t)nkt * mt_rows * 64 * 4;
   if (!c->d_mt) HIP_TRY(c, hipMalloc((void**)&c->d_mt, bytes));
   HIP_TRY(c, hipMemsetAsync(c->d_mt, 0, bytes, c->stream));
-  if (g.method == 1 && c->ie_quad) {
-    if (!c->d_mtq) HIP_TRY(c, hipMalloc((void**)&c->d_mtq, bytes));
-    HIP_TRY(c, hipMemsetAsync(c->d_mtq, 0, bytes, c->stream));
-  }
-  HIP_TRY(c, launch_build_mt(c->d_masks, 2 * g.Wp, g.Kpad, nkt, mt_rows, c->d_mt, c->d_mtq, c->stream));
+  HIP_TRY(c, launch_build_mt(c->d_masks, 2 * g.Wp, g.Kpad, nkt, mt_rows, c->d_mt, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->mask_epoch++;   // every count plane built so far belongs to the old masks
   c->win_k0 = 0;
@@ -1440,22 +1435,19 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (ia.seg_begin < ia.seg_end) {
             ia.queue = c->d_queue;
             ia.batch = c->ie_batch;
-            // method 1: the quad form (gcre_ieq.hip) wherever segments come in groups that join the same paths1 rows --
-            // every level but the one whose uids are the genes themselves (one uid per pivot)
+            // method 1, no plane output: the quad form (gcre_ieq.hip) wherever segments come in groups that join the same
+            // paths1 rows -- every level but the one whose uids are the genes themselves (one uid per pivot)
             bool quad = false;
-            // (it sums lists of up to 56 entries in registers: longer ones, here or in the recipe, keep the launch on k_null_ie_m1)
-            const bool short_lists = flags[5] <= 56u && (!use_rec || jp.p0->rec->max_len <= 56u);
-            if (g.method == 1 && c->d_ladder && c->ie_quad && c->d_mtq && short_lists && seg_entry &&
+            if (g.method == 1 && c->d_ladder && c->ie_quad && !ia.planes_out && seg_entry &&
                 ensure_quads(c, u, *seg_entry, ia.seg_begin) == GCRE_OK) {
               const int64_t nq = seg_entry->nquads - seg_entry->quad_begin;
-              quad = nq > 0 && ((ia.seg_end - ia.seg_begin) * 2 >= nq * 5 || c->ie_quad == 2);   // 2.5 segments per quad on average
+              quad = nq > 0 && ((ia.seg_end - ia.seg_begin) * 2 >= nq * 3 || c->ie_quad == 2);   // 1.5 segments per quad on average
               if (quad) {
-                ia.mtq = c->d_mtq + (size_t)(c->win_k0 / kSparseTile) * (size_t)(64 * g.Wp + 1) * 64;
                 ia.quads = seg_entry->d_quads;
                 ia.quad_begin = seg_entry->quad_begin;
                 ia.quad_end = seg_entry->nquads;
                 ia.batch = std::max(1, c->ie_batch / 2);   // a quad is up to four segments
-                const int wq = std::min(c->sparse_waves_per_cu, ieq_max_waves_per_cu(planes, ia.gz, ia.planes_out != nullptr, ia.rec_slot != nullptr));
+                const int wq = std::min(c->sparse_waves_per_cu, ieq_max_waves_per_cu(planes, ia.gz, ia.rec_slot != nullptr));
                 ia.waves_per_xcd = std::max(4, (dev_cus * wq / 8 / 4) * 4);
                 while (ia.waves_per_xcd > 4 && n * ie_tile_factor < (int64_t)8 * ia.waves_per_xcd * 128)
                   ia.waves_per_xcd = std::max(4, (ia.waves_per_xcd / 2 / 4) * 4);
@@ -1480,6 +1472,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
                            (long long)n, waves, tmv[7] / waves, tmv[0] / waves / 1e6, tmv[1] / waves / 1e6, tmv[2] / waves / 1e6, tmv[3] / waves / 1e6,
                            tmv[4] / waves / 1e6, tmv[5] / waves / 1e6, tmv[6] / waves / 1e6);
             else
+            std::fprintf(stderr, "[ie filter] uncertain path-tiles %llu of %lld x %d tiles, lanes that fetched rows %llu\n",
+                         (unsigned long long)tmv[1], (long long)n, ia.nkt, (unsigned long long)tmv[3]);
             std::fprintf(stderr, "[ie timing] paths %lld out %d waves %.0f: per-wave Mcycles seg %.2f load %.2f comp(incl load) %.2f lookup %.2f exch %.2f total %.2f, slowest wave %.2f\n",
                          (long long)n, ia.planes_out != nullptr, waves, tmv[0] / waves / 1e6, tmv[1] / waves / 1e6,
                          tmv[2] / waves / 1e6, tmv[3] / waves / 1e6, tmv[4] / waves / 1e6, tmv[5] / waves / 1e6, tmv[6] / 1e6);
@@ -1800,7 +1794,7 @@ void gcre_destroy(gcre_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void* p : {(void*)c->d_case_mask, (void*)c->d_masks, (void*)c->d_t32, (void*)c->d_dvt, (void*)c->d_dmax,
-                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_mtq, (void*)c->d_max_tot, (void*)c->d_queue, (void*)c->d_ladder})
+                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot, (void*)c->d_queue, (void*)c->d_ladder})
     if (p) (void)hipFree(p);
   for (auto* b : {&c->d_row0, &c->d_row1, &c->d_tot, &c->d_cases, &c->d_ctrls, &c->d_sel, &c->d_small, &c->d_chunk,
                   &c->d_rec_segs, &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})

@@ -328,6 +328,10 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
   for (int q = 0; q < 32; q++) nm[q * 64] = 0u;
   const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
+  // pinned to scalar registers (the compiler re-loads kernel arguments on both sides of the ticket's `lane == 0` branch
+  // and then treats them as divergent): the base of the added rows' planes, so that their loads take the scalar-base form
+  const char* k_planesz = (const char*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)((u64)a.planesz >> 32)) << 32) |
+                                        (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)a.planesz));
 
   int cur_kt = -1;
   u32 valid = 0u;
@@ -493,10 +497,12 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
           for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
         }
-        const u32x4* src = (const u32x4*)(a.planesz + (u64)rdlane(zunit, t2) * 256u) + lane;
+        // scalar base + 32-bit lane offset: the address never sits in vector registers (a vector address pair that shares
+        // registers with a load still in flight costs a full s_waitcnt vmcnt(0) per path)
+        __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(k_planesz + (u64)rdlane(zunit, t2) * 1024u), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int j = 0; j < GZ; j++) {
-          const u32x4 v = src[j * 64];
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rz, lane4 * 4u + (u32)j * 1024u, 0, 0);
           ZZ[4 * j + 0] = v.x; ZZ[4 * j + 1] = v.y; ZZ[4 * j + 2] = v.z; ZZ[4 * j + 3] = v.w;
         }
       };
@@ -729,7 +735,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
       // outside that narrower interval fetch the rows (exec-masked loads), finish the count and test it exactly; what
       // still falls outside [lo, hi] is looked up as before.  ~3/4 of the path-tiles end after 2 plane loads and ~45 bit
       // instructions.  (Delta lists -- rare since the inspector prefers overlap lists -- skip the filter.)
-      auto compute_f = [&](u32 t, const u32x8 o, const u32 (&Z)[4 * GZ]) {
+      auto compute_f = [&](u32 t, const u32 (&Z)[4 * GZ]) {
         const u32 r0 = rdlane(infov, t);
         const u32 len = r0 & kLinfoLenMask;
         const bool overlap = (r0 & 1u) != 0u;
@@ -767,7 +773,12 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
           for (int l = 0; l < L; l++) W[l] = B[l];
         }
         if (__builtin_amdgcn_ballot_w64(mu != 0u) == 0ull) return;
+#ifdef GCRE_IE_TIMING
+        tm[1] += 1;                                                            // path-tiles the filter left uncertain
+        tm[3] += (u64)__popcll(__builtin_amdgcn_ballot_w64(mu != 0u));         // ... and the lanes that fetched rows
+#endif
         u32 slow = 0u;
+        const u32x8 o = slots[t];
         if (mu != 0u) {
           // ---- the uncertain lanes: rows, exact count, exact test ----
           u32 y[8], S4[4];
@@ -862,16 +873,21 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
           }
         }
       } else {
-        // the planes of path t+1 are in flight while path t is tested; the list entries stay in scalar registers until
-        // their path has been tested
-        for (u32 t = 0; t < npaths; t += 2) {
-          issue(at(t + 1), oB, yB, ZB);
-          compute_f(t, oA, ZA);
+        // a filtered path is ~60 instructions: one path of work does not cover a plane load's latency, so the planes are
+        // requested TWO paths ahead (three buffers in rotation).  The list entries are only read by the few paths that
+        // fetch rows.
+        u32 ZC[4 * GZ];
+        issue(at(1u), oB, yB, ZB);
+        for (u32 t = 0; t < npaths; t += 3) {
+          issue(at(t + 2), oA, yA, ZC);
+          compute_f(t, ZA);
           if (t + 1 < npaths) {
-            oA = slots[at(t + 2)];
-            issue(at(t + 2), oA, yA, ZA);
-            compute_f(t + 1, oB, ZB);
-            oB = slots[at(t + 3)];
+            issue(at(t + 3), oA, yA, ZA);
+            compute_f(t + 1, ZB);
+          }
+          if (t + 2 < npaths) {
+            issue(at(t + 4), oA, yA, ZB);
+            compute_f(t + 2, ZC);
           }
         }
       }

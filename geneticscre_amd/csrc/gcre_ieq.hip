@@ -1,91 +1,64 @@
-// gcre_ieq.hip -- the pruned method-1 null kernel, "quad" form: one wave scores FOUR joined paths at a time.
+// gcre_ieq.hip -- the pruned method-1 null kernel, "quad" form: one wave works on up to FOUR segments at a time that
+// join the same paths1 rows, and fetches the planes of every added row once for all of them.
 //
-// Same arithmetic as k_null_ie_m1 (gcre_ie.hip): for every joined path and 2048-permutation tile
+// Same arithmetic and the same lane layout as k_null_ie_m1 (gcre_ie.hip; lane = 32 permutations of a 2048-permutation
+// tile): for every joined path
 //
 //     count = N0[idx] + Nz[z] - popc(p0[idx] & z & mask_r)        (bit-sliced, reference src/methods.h:73-88)
 //
-// followed by the exact interval test against the pruning ladder and table look-ups (methods.h:96-103) only for the
-// permutations that fail it.  What changes is how the operands reach the lanes.  k_null_ie_m1 gives every lane 32
-// permutations of ONE path, so each of the 8 mask rows of a path is a 256-byte wave load of 4 bytes per lane -- and a
-// CU's vector-memory pipe takes ~15 clocks per wave-load whatever its width (tools/row_gather_rate.hip): 8 row loads +
-// 2 plane loads per path-tile = 146 CU-clocks, the measured cost of that kernel.  It is bound by the number of
-// vector-memory INSTRUCTIONS, not by bytes, VALU issue or latency.
+// tested against the pruning ladder's interval [lo, hi] of the path's table diagonal; only what falls outside is looked
+// up (methods.h:96-103).  With the bound filter (W = N0 + Nz against [lo + ov, hi], see k_null_ie_m1) nine path-tiles in
+// ten never read a mask row, and what is left of k_null_ie_m1's vector-memory traffic is dominated by the two 1-KB plane
+// loads of the added row per path-tile: the kernel is bound by the CU's vector-memory pipe at ~20 clocks per wave-load
+// (tools/row_gather_rate.hip), not by VALU issue and not by bytes.
 //
-// Here a wave is four groups of 16 lanes.  Group g works on its own uid (segment); lane (g, s) holds FOUR dwords --
-// 128 permutations -- of every row and plane of its group's path: dwords w = s + 16 d, d = 0..3, of the 64-dword tile.
-//   * mask rows: one buffer_load_dwordx4 fetches one row for each of the four paths (16 lanes x 16 B = 256 B per group,
-//     from a copy of the transposed masks whose dwords are stored in lane order, `mtq`): 8 loads per FOUR path-tiles,
-//     ~19 clocks each instead of 4 x 15;
-//   * added rows: the four segments of a quad join the SAME paths1 rows (all uids with one pivot gene do: the host
-//     groups them, gcre_host.hip quad table), so the planes of the added row are loaded once per wave (GZ wide loads)
-//     and handed to the four groups through LDS;
-//   * per-path metadata (list slot, list info, carrier total, ladder entry, added row) is staged through LDS sixteen
-//     paths at a time, read back with broadcast ds_read_b128 -- nothing is moved through scalar registers.
-// VALU work per path-tile is unchanged (every instruction still processes 64 x 32 counters); vector-memory
-// instructions drop from 13 to ~3 per path-tile.
+// All uids with the same pivot gene join the same paths1 rows (the join index gives them the same location and count), so
+// their segments walk the same sequence of added rows.  The host groups up to four such segments into a quad
+// (gcre_host.hip ensure_quads).  The wave keeps the base counters of all four (4 x L registers) and, for every position
+// t of the shared sequence, loads Nz[z_t] once and scores path t of each segment against it: the plane loads per
+// path-tile drop from 2 to 0.5, the instruction stream per path-tile is unchanged.
 #include "gcre_ie_common.h"
 
 namespace gcre {
 
-constexpr int kQChunk = 16;       // joined paths (per group) whose metadata is staged at a time
-constexpr int kQMeta = 12;        // words per staged path: slot[8], linfo, tot, lover, added row
-constexpr int kQS = 6;            // planes of a list's row sum: lists of up to 56 entries (the host sends longer ones to k_null_ie_m1)
+constexpr int kQSegs = 4;
 
-typedef u32 __attribute__((ext_vector_type(3))) u32x3;
-
-// (a & m) | (b & ~m)
-__device__ __forceinline__ u32 mux3(u32 a, u32 b, u32 m) { return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4); }
-
-// -DGCRE_IE_TIMING: per-section s_memtime sums (no extra waits: a mark only reads the clock)
-#ifdef GCRE_IE_TIMING
-#define GCRE_QT(var) const u64 var = __builtin_amdgcn_s_memtime()
-#define GCRE_QT_ADD(i, t1, t0) tm[i] += (t1) - (t0)
-#else
-#define GCRE_QT(var)
-#define GCRE_QT_ADD(i, t1, t0)
-#endif
-
-template <int L, int GZ, bool OUT, bool REC>
-__global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2))) void k_null_ie_q(const IeArgs a) {
+template <int L, int GZ, bool REC>
+__global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3))) void k_null_ie_q(const IeArgs a) {
   constexpr int LP = (L + 3) / 4 * 4;
   constexpr int LZ = 4 * GZ;
   static_assert(L >= 8 && L <= 16 && GZ >= 2 && LZ <= LP, "planes come in groups of 4");
-  __shared__ u32 nmax_lds[kIeWaves][32 * 64];                       // running maxima [bit][dword] per wave
-  __shared__ u32x4 z_lds[kIeWaves][GZ * 64];                        // planes of the added row of the current iteration
-  __shared__ u32x4 meta_lds[kIeWaves][64 * kQMeta / 4];             // [group][path of the chunk][kQMeta words]
+  typedef u32 __attribute__((ext_vector_type(8))) u32x8;
+  __shared__ u32 nmax_lds[kIeWaves][32 * 64];   // the waves' running maxima [bit][lane]
   __shared__ u32 wq_state[kIeWaves][8];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = lane >> 4, sub = lane & 15;
-  // Launch constants that steer control flow or end up in buffer descriptors, pinned to scalar registers here: the
-  // compiler re-loads kernel arguments on both sides of the `lane == 0` branch around the ticket atomic, and whatever is
-  // derived from such a pair counts as divergent (waterfall loops around every buffer load, vector-register loop counters).
-  auto uni = [](u32 v) -> u32 { return (u32)__builtin_amdgcn_readfirstlane((int)v); };
-  const u32 k_quad_begin = uni((u32)a.quad_begin), k_quad_end = uni((u32)a.quad_end), k_batch = uni((u32)a.batch);
-  const u32 k_nkt = uni((u32)a.nkt), k_K = uni((u32)a.K), k_mt_rows = uni(a.mt_rows), k_lstride = uni((u32)a.ladder_stride);
-  const u32 k_lad_mode = uni((u32)a.lad_mode), k_score_segs = uni(a.score_segs);
-  const u32* k_mtq = (const u32*)(((u64)uni((u32)((u64)a.mtq >> 32)) << 32) | (u64)uni((u32)(u64)a.mtq));
+  const u32 lane4 = (u32)lane * 4u;
   u32* nm = nmax_lds[wave] + lane;
 #pragma unroll
   for (int q = 0; q < 32; q++) nm[q * 64] = 0u;
-  u32x4* zst = z_lds[wave];
-  u32x4* mst = meta_lds[wave];
-  const SparseSeg* segs = a.segs;
+  // Launch constants that steer control flow or end up in buffer descriptors, pinned to scalar registers: the compiler
+  // re-loads kernel arguments on both sides of the `lane == 0` branch around the ticket atomic, and whatever is derived
+  // from such a pair counts as divergent (waterfall loops around buffer loads, vector-register loop counters).
+  auto uni = [](u32 v) -> u32 { return (u32)__builtin_amdgcn_readfirstlane((int)v); };
+  auto uni_ptr = [&](const void* p) -> const char* { return (const char*)(((u64)uni((u32)((u64)p >> 32)) << 32) | (u64)uni((u32)(u64)p)); };
+  const u32 k_quad_begin = uni((u32)a.quad_begin), k_quad_end = uni((u32)a.quad_end), k_batch = uni((u32)a.batch);
+  const u32 k_nkt = uni((u32)a.nkt), k_K = uni((u32)a.K), k_mt_rows = uni(a.mt_rows), k_lstride = uni((u32)a.ladder_stride);
+  const u32 k_lad_mode = uni((u32)a.lad_mode), k_score_segs = uni(a.score_segs);
+  const char* k_mt = uni_ptr(a.mt);
+  const char* k_planesz = uni_ptr(a.planesz);
+  const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
 
   int cur_kt = -1;
-  u32 valid = 0u;          // exchange(): lane = dword `lane` of the tile
-  bool tail_tile = false;  // the tile holds fewer than 2048 live permutations
+  u32 valid = 0u;
   u32 lad_base = (k_lad_mode == 0u) ? 0u : ((u32)kLadderLevels - 1u + k_lad_mode) * k_lstride;
   const u32 lad_keep = (u32)kLadderLevels * k_lstride;
   bool dirty = false;
   u32 n_slow = 0u;
-#ifdef GCRE_IE_TIMING
-  u64 tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // quad header + base counters, row sums (incl. the wait for the rows), long lists, fetch, counts + test, look-ups, total, iterations
-  const u64 tm_begin = __builtin_amdgcn_s_memtime();
-#endif
-  __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)k_mtq, 0, 0x7fffffff, 0x00020000);
-  const u32 sub16 = (u32)sub * 16u;
+  __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)k_mt, 0, 0x7fffffff, 0x00020000);
 
+  // publish the wave's maxima, read everybody's, set the threshold level to the smallest running maximum of the tile's
+  // live permutations (a stale read only lowers it: still exact)
   auto exchange = [&]() {
     u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
     __amdgpu_buffer_rsrc_t nb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.null_bits + (size_t)cur_kt * 2048), 0, 8192, 0x00020000);
@@ -145,412 +118,386 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(2
     if (kt != cur_kt) {
       flush_tile();
       cur_kt = kt;
-      mt = __builtin_amdgcn_make_buffer_rsrc((void*)(k_mtq + (size_t)kt * k_mt_rows * 64), 0, 0x7fffffff, 0x00020000);
+      mt = __builtin_amdgcn_make_buffer_rsrc((void*)(k_mt + (size_t)kt * k_mt_rows * 256u), 0, 0x7fffffff, 0x00020000);
       const int live = (int)k_K - kt * 2048 - lane * 32;
       valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
-      tail_tile = (int)k_K - kt * 2048 < 2048;
       if (k_lad_mode == 0u) lad_base = 0u;
       since = 0;
       period = 1;
     }
     for (u32 qi = q_lo; qi < q_hi; qi++) {
-      // ---- the quad: up to four consecutive segments that join the same paths1 rows; spare groups shadow the last one
-      GCRE_QT(tq0);
-      const u32 qe = a.quads[qi];
+      // ---- the quad: up to four consecutive segments of the table, same added rows, same length ----
+      const u32 qe = uni(((const u32 GCRE_CONSTANT*)a.quads)[qi]);
       const u32 qcnt = (qe >> 30) + 1u;
-      const u32 sidx = (qe & 0x3fffffffu) + ((u32)grp < qcnt ? (u32)grp : qcnt - 1u);
-      const u32* sgp = (const u32*)segs + (u64)sidx * 3u;
-      const u32 row0 = sgp[0], first = sgp[1];
-      const u32 npaths = __builtin_amdgcn_readfirstlane(sgp[2]);   // the segments of a quad have the same length
-      u32x4 rc0 = {0u, 0u, 0u, 0u}, rc1 = rc0, rc2 = rc0;
-      if constexpr (REC) {
-        const u32x4* rs = (const u32x4*)(a.rec_segs + (u64)sidx * kRecSegWords);
-        rc0 = rs[0];   // paths0 row of the producing join, row it added, list info, where a long list continues
-        rc1 = rs[1];   // its slot
-        rc2 = rs[2];
-      }
+      const u32 s0 = qe & 0x3fffffffu;
+      const u32 npaths = uni(segs[s0].n);
+      const u32 last = npaths - 1u;
       if (k_lad_mode == 0u && ++since >= period) {
         exchange();
         since = 0;
         period = period < kIeRefresh ? period * 2 : kIeRefresh;
       }
-      const u32 lad_row = (sidx < k_score_segs) ? lad_base : lad_keep;
-      const u32 last = npaths - 1u;
+      const u32 lad_row = (s0 < k_score_segs) ? lad_base : lad_keep;
 
-      // ---- metadata of 16 paths per group: lane (g, s) fetches path first_g + j0 + s ----
-      auto stage_load = [&](u32 j0, u32 (&M)[kQMeta]) {
-        const u32 jj = j0 + (u32)sub;
-        const u64 p = (u64)first + (jj < last ? jj : last);
-        const u32x4* sl = (const u32x4*)(a.dlist + p * 8u);
-        const u32x4 e0 = sl[0], e1 = sl[1];
-        M[0] = e0.x; M[1] = e0.y; M[2] = e0.z; M[3] = e0.w;
-        M[4] = e1.x; M[5] = e1.y; M[6] = e1.z; M[7] = e1.w;
-        M[8] = a.linfo[p];
-        M[9] = a.tot[p];
-        M[10] = a.lover[p];
-        M[11] = a.rowz[p] & 0x7fffffffu;
-      };
-      auto stage_store = [&](u32 (&M)[kQMeta]) {
-        u32x4* dst = mst + lane * (kQMeta / 4);
-        dst[0] = u32x4{M[0], M[1], M[2], M[3]};
-        dst[1] = u32x4{M[4], M[5], M[6], M[7]};
-        dst[2] = u32x4{M[8], M[9], M[10], M[11]};
-      };
-      // What the lanes of a group need of their path j.  Everything that has to come from memory for it goes out one path
-      // ahead: the 8 rows of its slot, the added row's planes, its ladder entry and -- when its list is longer than the
-      // slot -- the next 8 entries of the list.
-      struct PathMeta { u32 info, tot, lh, rowz, lov; u32x4 e2a, e2b; };
-      auto fetch = [&](u32 jn, PathMeta& pm, u32x4 (&yy)[8], u32x4 (&zz)[GZ]) {
-        const u32 jc = jn < last ? jn : last;   // past the end: the last path is simply requested again
-        const u32x4* src = mst + (grp * kQChunk + (int)(jc & (kQChunk - 1))) * (kQMeta / 4);
-        const u32x4 e0 = src[0], e1 = src[1], e2 = src[2];
-        pm.info = e2.x; pm.tot = e2.y; pm.lov = e2.z; pm.rowz = e2.w;
-        const u32 offs[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+      // ---- per segment: the metadata of its paths (lane t <-> path first + t) and its base counters ----
+      u32 infov[kQSegs], lhv[kQSegs], lfv[kQSegs], firstg[kQSegs];
+      u32 B[kQSegs][L];
+      u32 zunit = 0u;
+      auto load_groups = [&](u32 (&P)[LP], const u32* planes, u64 unit, int groups) {
+        __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(uni_ptr(planes) + unit * 1024u), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < 8; k++) yy[k] = __builtin_amdgcn_raw_buffer_load_b128(mt, offs[k] + sub16, 0, 0);
-        // the added row is the same for the four groups: group 0's copy of its number addresses the (wave-wide) loads
-        const u32 zunit = ((u32)kt * (u32)a.rowsz + __builtin_amdgcn_readfirstlane(pm.rowz)) * (u32)a.gz;
-        const u32x4* zsrc = (const u32x4*)(a.planesz + (u64)zunit * 256u) + lane;
-#pragma unroll
-        for (int jz = 0; jz < GZ; jz++) zz[jz] = zsrc[jz * 64];
-        pm.lh = a.ladder[lad_row + pm.tot];
-        pm.e2a = pm.e2b = u32x4{a.zoff, a.zoff, a.zoff, a.zoff};
-        if (__builtin_amdgcn_ballot_w64((pm.info & kLinfoLenMask) > 8u) != 0ull) {   // somebody's list goes on (lists start 32-byte aligned)
-          const u32x4* more = (const u32x4*)(a.dover + ((pm.info & kLinfoLenMask) > 8u ? pm.lov : 0u));
-          const u32x4 ma = more[0], mb = more[1];
-          if ((pm.info & kLinfoLenMask) > 8u) { pm.e2a = ma; pm.e2b = mb; }
+        for (int j = 0; j < LP / 4; j++) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (j < groups) v = __builtin_amdgcn_raw_buffer_load_b128(rp, lane4 * 4u + (u32)j * 1024u, 0, 0);
+          P[4 * j + 0] = v.x; P[4 * j + 1] = v.y; P[4 * j + 2] = v.z; P[4 * j + 3] = v.w;
         }
       };
-      // the rest of a list: 8 more rows per round, every round summed into the planes S; groups that are through add the
-      // all-zero row.  y2 = the rows of entries 8..15, already requested by the caller (or nullptr: fetch them here)
-      auto add_blocks = [&](u32 (&S)[kQS][4], u32 len, u32 maxlen, const u32* over, u32 lov, const u32x4 (*y2p)[8]) {
-        for (u32 q = 8u; q < maxlen; q += 8u) {
-          u32x4 y2[8];
-          if (q == 8u && y2p) {
+      // (a) everything the quad's segments need from memory goes out together: their paths' metadata, the planes their
+      // base counters start from and -- with a recipe -- the mask rows of the producing join's list.  One round trip per
+      // quad, not one per segment.
+      u32 totv[kQSegs];
+      u32 yr[REC ? kQSegs : 1][8];
+      u32 rinfo_g[kQSegs] = {0u, 0u, 0u, 0u}, rlov_g[kQSegs] = {0u, 0u, 0u, 0u}, rz_g[kQSegs] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int k = 0; k < 8; k++) y2[k] = (*y2p)[k];
+      for (int g = 0; g < kQSegs; g++) {
+        if ((u32)g < qcnt) {
+          const u32 sidx = s0 + (u32)g;
+          const u32 row0 = uni(segs[sidx].row0), first = uni(segs[sidx].first);
+          firstg[g] = first;
+          const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
+          infov[g] = a.linfo[qv];
+          totv[g] = a.tot[qv];
+          if (g == 0) zunit = ((u32)kt * (u32)a.rowsz + (a.rowz[qv] & 0x7fffffffu)) * (u32)a.gz;   // the same for every segment of the quad
+          u32 Bp[LP];
+          if constexpr (!REC) {
+            load_groups(Bp, a.planes0, ((u64)kt * (u64)a.rows0 + (u64)row0) * (u64)a.g0, a.g0);
           } else {
-            const u32x4* more = (const u32x4*)(over + (q < len ? lov + q - 8u : 0u));
-            const u32x4 ma = more[0], mb = more[1];
-            const bool in = q < len;
-            const u32 o8[8] = {in ? ma.x : a.zoff, in ? ma.y : a.zoff, in ? ma.z : a.zoff, in ? ma.w : a.zoff,
-                               in ? mb.x : a.zoff, in ? mb.y : a.zoff, in ? mb.z : a.zoff, in ? mb.w : a.zoff};
+            // the segment's recipe words sit next to the segment table (k_fill_rec_segs): paths0 row of the producing
+            // join, row it added, list info, where a long list continues, the list's first 8 entries
+            const u32 GCRE_CONSTANT* rs = (const u32 GCRE_CONSTANT*)a.rec_segs + (u64)sidx * kRecSegWords;
+            const u32 ra = uni(rs[0]);
+            rz_g[g] = uni(rs[1]) & 0x7fffffffu;
+            rinfo_g[g] = uni(rs[2]);
+            rlov_g[g] = uni(rs[3]);
+            const u32x8 ro = *(const u32x8 GCRE_CONSTANT*)(rs + 4);
+            const u32 rtrue = (rinfo_g[g] & kLinfoLenMask) - (rinfo_g[g] >> 28);   // entries that are not padding
 #pragma unroll
-            for (int k = 0; k < 8; k++) y2[k] = __builtin_amdgcn_raw_buffer_load_b128(mt, o8[k] + sub16, 0, 0);
+            for (int j = 0; j < 8; j++) {
+              yr[REC ? g : 0][j] = 0u;
+              if ((u32)j < rtrue) yr[REC ? g : 0][j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, uni(ro[j]), 0);
+            }
+            load_groups(Bp, a.rec_planes_a, ((u64)kt * (u64)a.rec_rows_a + (u64)ra) * (u64)a.rec_ga, a.rec_ga);
           }
 #pragma unroll
-          for (int d = 0; d < 4; d++) {
-            u32 r8[8], s4[4];
+          for (int l = 0; l < L; l++) B[g][l] = Bp[l];
+        }
+      }
+      // (b) with a recipe: row = A + Z -/+ list.  The segments of a quad end in the same pivot gene, so the row the
+      // producing join added -- that gene -- is the same for all of them: its planes are loaded once
+      if constexpr (REC) {
+        u32 ZR[LP];
+        load_groups(ZR, a.rec_planes_z, ((u64)kt * (u64)a.rec_rows_z + (u64)rz_g[0]) * (u64)a.rec_gz, a.rec_gz);
 #pragma unroll
-            for (int k = 0; k < 8; k++) r8[k] = y2[k][d];
-            sum8(r8, s4);
+        for (int g = 0; g < kQSegs; g++) {
+          if ((u32)g < qcnt) {
+            if (rz_g[g] != rz_g[0]) load_groups(ZR, a.rec_planes_z, ((u64)kt * (u64)a.rec_rows_z + (u64)rz_g[g]) * (u64)a.rec_gz, a.rec_gz);
+            const u32 rinfo = rinfo_g[g];
+            const u32 rlen = rinfo & kLinfoLenMask;
+            u32 S[L];
+            {
+              u32 S4[4];
+              sum8(yr[REC ? g : 0], S4);
+#pragma unroll
+              for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
+            }
+            if (rlen > 8u) {   // the producing join's list was long: the rest of it, 8 entries at a time
+              const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.rec_over + rlov_g[g]);
+              for (u32 p = 0u; p + 8u < rlen; p += 8u) {
+                const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
+                u32 yy[8], s4[4];
+#pragma unroll
+                for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, uni(o8[j]), 0);
+                sum8(yy, s4);
+                u32 cy = 0u;
+#pragma unroll
+                for (int l = 0; l < L; l++) {
+                  const u32 sv = S[l];
+                  const u32 add = (l < 4) ? s4[l < 4 ? l : 0] : 0u;
+                  S[l] = xor3(sv, add, cy);
+                  cy = majority(sv, add, cy);
+                }
+              }
+            }
+            if (rinfo & 1u) {   // B = A + Z - S
+              u32 cy = 0u, bw = 0u;
+#pragma unroll
+              for (int l = 0; l < L; l++) {
+                const u32 s1_ = xor3(B[g][l], ZR[l], cy);
+                cy = majority(B[g][l], ZR[l], cy);
+                B[g][l] = xor3(s1_, S[l], bw);
+                bw = borrow3(s1_, S[l], bw);
+              }
+            } else {            // B = A + S
+              u32 cy = 0u;
+#pragma unroll
+              for (int l = 0; l < L; l++) {
+                const u32 bl = B[g][l];
+                B[g][l] = xor3(bl, S[l], cy);
+                cy = majority(bl, S[l], cy);
+              }
+            }
+            if (rz_g[g] != rz_g[0]) load_groups(ZR, a.rec_planes_z, ((u64)kt * (u64)a.rec_rows_z + (u64)rz_g[0]) * (u64)a.rec_gz, a.rec_gz);
+          }
+        }
+      }
+      // (c) the filter's interval per path, ready to use: [lo + ov, hi] packed as hi << 16 | lo; the empty interval (lo 1,
+      // hi 0: "everything is outside") for delta lists and for bounds the margin pushes out of range
+#pragma unroll
+      for (int g = 0; g < kQSegs; g++) {
+        if ((u32)g < qcnt) {
+          const u32 lh = a.ladder[lad_row + totv[g]];
+          const u32 r0 = infov[g];
+          const u32 ov = (r0 & kLinfoLenMask) - (r0 >> 28);
+          const u32 lo = lh & 0xffffu;
+          const u32 lo2 = lo ? lo + ov : 0u;              // counts are never negative: lo = 0 needs no margin
+          lhv[g] = lh;
+          lfv[g] = ((r0 & 1u) == 0u || (lo2 >> L) != 0u) ? 1u : ((lh & 0xffff0000u) | lo2);
+        }
+      }
+
+      const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)a.dlist;
+      auto issue = [&](u32 t2, u32 (&ZZ)[LZ]) {
+        __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(k_planesz + (u64)rdlane(zunit, t2) * 1024u), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < GZ; j++) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rz, lane4 * 4u + (u32)j * 1024u, 0, 0);
+          ZZ[4 * j + 0] = v.x; ZZ[4 * j + 1] = v.y; ZZ[4 * j + 2] = v.z; ZZ[4 * j + 3] = v.w;
+        }
+      };
+      auto at = [&](u32 t2) -> u32 { return t2 < last ? t2 : last; };
+
+      // ---- first pass: the bound filter.  Path t of segment g against the planes Z of the row the quad's segments all
+      // add: W = B_g + Z is inside [lo + ov, hi] for every live permutation <=> no count of the path can raise a maximum
+      // whatever its overlap rows say.  Paths that fail (about one in ten) -- and the rare delta-list paths -- are only
+      // marked, one bit per path in a scalar mask per segment: nothing in this loop waits for anything but the planes.
+      u64 todo[kQSegs] = {0ull, 0ull, 0ull, 0ull};
+      auto filter_f = [&](int g, u32 t, const u32 (&Bg)[L], const u32 (&Z)[LZ]) {
+        const u32 lf = rdlane(lfv[g], t);   // hi << 16 | lo + ov
+        u32 cy = 0u, blo = 0u, bhi = 0u;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          u32 w;
+          if (l < LZ) {
+            w = xor3(Bg[l], Z[l < LZ ? l : 0], cy);
+            cy = majority(Bg[l], Z[l < LZ ? l : 0], cy);
+          } else {
+            w = Bg[l] ^ cy;
+            cy = Bg[l] & cy;
+          }
+          const u32 kl = (u32)__builtin_amdgcn_sbfe((int)lf, l, 1);
+          const u32 kh = (u32)__builtin_amdgcn_sbfe((int)lf, 16 + l, 1);
+          blo = borrow3(w, kl, blo);    // W < lo + ov
+          bhi = borrow3(kh, w, bhi);    // W > hi
+        }
+        if (__builtin_amdgcn_ballot_w64(((blo | bhi) & valid) != 0u) != 0ull) todo[g] |= 1ull << t;
+      };
+
+      // the planes of the next added row are in flight while up to four paths are tested against the current one
+#ifdef GCRE_IEQ_NOPATHS   // diagnostics: what the per-segment work alone costs (results are wrong)
+      if (B[0][0] == 0x12345678u && B[1][1] == 1u && B[2][2] == 2u && B[3][3] == 3u)
+#endif
+      {
+        u32 ZA[LZ], ZB[LZ];
+        issue(0u, ZA);
+        for (u32 t = 0; t < npaths; t += 2) {
+          issue(at(t + 1), ZB);
+#pragma unroll
+          for (int g = 0; g < kQSegs; g++)
+            if ((u32)g < qcnt) filter_f(g, t, B[g], ZA);
+          if (t + 1 < npaths) {
+            issue(at(t + 2), ZA);
+#pragma unroll
+            for (int g = 0; g < kQSegs; g++)
+              if ((u32)g < qcnt) filter_f(g, t + 1, B[g], ZB);
+          }
+        }
+      }
+
+      // ---- second pass: the marked paths, exactly.  The planes of the added row again, the mask rows of the list's real
+      // entries, count = B + Nz - S (or B + S), the interval test, look-ups for what falls outside -- with the loads of
+      // the next marked path in flight while this one is computed.
+      struct Item { u32 info, lov, tot, lh; u32x8 o; };
+      auto item_meta = [&](int g, u32 t) -> Item {
+        Item it;
+        const u64 q = (u64)firstg[g] + t;
+        it.info = rdlane(infov[g], t);
+        it.lh = rdlane(lhv[g], t);
+        it.lov = ((const u32 GCRE_CONSTANT*)a.lover)[q];
+        it.tot = ((const u32 GCRE_CONSTANT*)a.tot)[q];
+        it.o = slots[q];
+        return it;
+      };
+      auto item_issue = [&](const Item& it, u32 t, u32 (&yy)[8], u32 (&ZZ)[LZ]) {
+        const u32 ov = (it.info & kLinfoLenMask) - (it.info >> 28);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          yy[j] = 0u;
+          if ((u32)j < ov) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, it.o[j], 0);   // padding entries are not fetched
+        }
+        if (it.info & 1u) issue(t, ZZ);
+      };
+      auto exact_f = [&](const Item& it, const u32 (&Bg)[L], const u32 (&y)[8], const u32 (&Z)[LZ]) {
+        const u32 len = it.info & kLinfoLenMask;
+        const bool overlap = (it.info & 1u) != 0u;
+        const u32 lo = it.lh & 0xffffu, hi = it.lh >> 16;
+        u32 S4[4];
+        sum8(y, S4);
+        u32 S[L];
+#pragma unroll
+        for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
+        if (len > 8u) {   // long list: further blocks of 8 entries
+          const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + it.lov);
+          for (u32 p = 0u; p + 8u < len; p += 8u) {
+            const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
+            u32 yy[8], s4[4];
+#pragma unroll
+            for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o8[j], 0);
+            sum8(yy, s4);
             u32 cy = 0u;
 #pragma unroll
-            for (int l = 0; l < kQS; l++) {
-              const u32 sv = S[l][d];
+            for (int l = 0; l < L; l++) {
+              const u32 sv = S[l];
               if (l < 4) {
-                S[l][d] = xor3(sv, s4[l < 4 ? l : 0], cy);
+                S[l] = xor3(sv, s4[l < 4 ? l : 0], cy);
                 cy = majority(sv, s4[l < 4 ? l : 0], cy);
               } else {
-                S[l][d] = sv ^ cy;
+                S[l] = sv ^ cy;
                 cy = sv & cy;
               }
             }
           }
         }
-      };
-
-      u32 M0[kQMeta];
-      stage_load(0u, M0);
-
-      // ---- base counters of the four groups' paths0 rows: stored planes, or (REC) rebuilt from the recipe ----
-      u32 B[L][4];
-      auto load_groups = [&](u32 (&P)[LP][4], const u32* planes, u64 unit, int groups) {
-        const u32x4* src = (const u32x4*)(planes + unit * 256u) + sub;
-#pragma unroll
-        for (int j = 0; j < LP / 4; j++) {
-#pragma unroll
-          for (int d = 0; d < 4; d++) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (j < groups) v = src[j * 64 + 16 * d];
-            P[4 * j + 0][d] = v.x; P[4 * j + 1][d] = v.y; P[4 * j + 2][d] = v.z; P[4 * j + 3][d] = v.w;
-          }
-        }
-      };
-      if constexpr (!REC) {
-        u32 P[LP][4];
-        load_groups(P, a.planes0, ((u64)kt * (u64)a.rows0 + (u64)row0) * (u64)a.g0, a.g0);
-#pragma unroll
-        for (int l = 0; l < L; l++)
-#pragma unroll
-          for (int d = 0; d < 4; d++) B[l][d] = P[l][d];
-      } else {
-        const u32 ra = rc0.x, rz = rc0.y & 0x7fffffffu, rinfo = rc0.z, rlov = rc0.w;
-        const u32 ro[8] = {rc1.x, rc1.y, rc1.z, rc1.w, rc2.x, rc2.y, rc2.z, rc2.w};
-        u32x4 yr[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) yr[k] = __builtin_amdgcn_raw_buffer_load_b128(mt, ro[k] + sub16, 0, 0);
-        u32 A[LP][4], ZR[LP][4];
-        load_groups(A, a.rec_planes_a, ((u64)kt * (u64)a.rec_rows_a + (u64)ra) * (u64)a.rec_ga, a.rec_ga);
-        load_groups(ZR, a.rec_planes_z, ((u64)kt * (u64)a.rec_rows_z + (u64)rz) * (u64)a.rec_gz, a.rec_gz);
-        const u32 mo = (rinfo & 1u) ? 0xffffffffu : 0u;   // the producing join's list: overlap (A + Z - S) or delta (A + S)
-        const u32 rlen = rinfo & kLinfoLenMask;
-        u32 S[kQS][4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          u32 r8[8], S4[4];
-#pragma unroll
-          for (int k = 0; k < 8; k++) r8[k] = yr[k][d];
-          sum8(r8, S4);
-#pragma unroll
-          for (int l = 0; l < kQS; l++) S[l][d] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
-        }
-        if (__builtin_amdgcn_ballot_w64(rlen > 8u) != 0ull)   // rare: a long list in the recipe
-          add_blocks(S, rlen, __builtin_amdgcn_readfirstlane(wave_max_u32(rlen)), a.rec_over, rlov, nullptr);
-        // T = X - Y with (X, Y) = (Z, S) for an overlap list, (S, 0) for a delta list; B = A + T
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          u32 bw = 0u, cy = 0u;
+        u32 C[L];
+        if (overlap) {   // C = B + Nz - S
+          u32 cy = 0u, bw = 0u;
 #pragma unroll
           for (int l = 0; l < L; l++) {
-            const u32 sl = (l < kQS) ? S[l < kQS ? l : 0][d] : 0u;
-            const u32 X = mux3(ZR[l][d], sl, mo);
-            const u32 Y = sl & mo;
-            const u32 T = xor3(X, Y, bw);
-            bw = borrow3(X, Y, bw);
-            B[l][d] = xor3(A[l][d], T, cy);
-            cy = majority(A[l][d], T, cy);
+            const u32 zl = (l < LZ) ? Z[l < LZ ? l : 0] : 0u;
+            const u32 w = xor3(Bg[l], zl, cy);
+            cy = majority(Bg[l], zl, cy);
+            C[l] = xor3(w, S[l], bw);
+            bw = borrow3(w, S[l], bw);
+          }
+        } else {         // C = B + S
+          u32 cy = 0u;
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            C[l] = xor3(Bg[l], S[l], cy);
+            cy = majority(Bg[l], S[l], cy);
           }
         }
-      }
-
-      // ---- first chunk of metadata into LDS, first path's loads on their way ----
-      stage_store(M0);
-      PathMeta pm;
-      u32x4 y[8], zg[GZ];
-      fetch(0u, pm, y, zg);
-
-      // ---- one joined path per group and iteration.  The rows are summed first (they leave their registers), then the
-      // next path's loads go out, then the counts are put together and tested: one set of row buffers.
-      GCRE_QT(tq1);
-      GCRE_QT_ADD(0, tq1, tq0);
-      for (u32 j = 0; j < npaths; j++) {
-        GCRE_QT(ti0);
-        // the added row's planes to LDS: lane l holds dword l of GZ plane groups; lane (g, s) reads dwords s + 16 d
-#pragma unroll
-        for (int jz = 0; jz < GZ; jz++) zst[jz * 64 + lane] = zg[jz];
-        const u32 info = pm.info, tot = pm.tot, lh = pm.lh;
-        const u32 len = info & kLinfoLenMask;
-        const u32 mo = (info & 1u) ? 0xffffffffu : 0u;
-        const bool all_overlap = __builtin_amdgcn_ballot_w64((info & 1u) == 0u) == 0ull;
-        // 10-20 % of the paths: some group's list is longer than its slot.  The rows of its entries 8..15 (the entries came
-        // with the path's other loads) go out before the slot's rows are summed
-        const bool any_long = __builtin_amdgcn_ballot_w64(len > 8u) != 0ull;
-        u32x4 y2[8];
-        if (any_long) {
-          const u32 o8[8] = {pm.e2a.x, pm.e2a.y, pm.e2a.z, pm.e2a.w, pm.e2b.x, pm.e2b.y, pm.e2b.z, pm.e2b.w};
-#pragma unroll
-          for (int k = 0; k < 8; k++) y2[k] = __builtin_amdgcn_raw_buffer_load_b128(mt, o8[k] + sub16, 0, 0);
-        }
-        const u32 lov = pm.lov;
-        u32 S[kQS][4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          u32 r8[8], S4[4];
-#pragma unroll
-          for (int k = 0; k < 8; k++) r8[k] = y[k][d];
-          sum8(r8, S4);
-#pragma unroll
-          for (int l = 0; l < kQS; l++) S[l][d] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
-        }
-        GCRE_QT(ti1);
-        GCRE_QT_ADD(1, ti1, ti0);
-        if (any_long) add_blocks(S, len, __builtin_amdgcn_readfirstlane(wave_max_u32(len)), a.dover, lov, &y2);
-        GCRE_QT(ti2);
-        GCRE_QT_ADD(2, ti2, ti1);
-        // ---- the next path's loads; at a chunk boundary the next 16 paths' metadata has to be in LDS first (the row
-        // buffers are free at this point: the staging registers cost nothing; one exposed round trip per 16 paths)
-        if (((j + 1u) & (kQChunk - 1)) == 0u && j + 1u < npaths) {
-          u32 Mn[kQMeta];
-          stage_load(j + 1u, Mn);
-          stage_store(Mn);
-        }
-        fetch(j + 1u, pm, y, zg);
-        GCRE_QT(ti3);
-        GCRE_QT_ADD(3, ti3, ti2);
-
-        const u32 lo = lh & 0xffffu, hi = lh >> 16;
-        u32 kl[L], kh[L];
+        u32 blo = 0u, bhi = 0u;
 #pragma unroll
         for (int l = 0; l < L; l++) {
-          kl[l] = (u32)__builtin_amdgcn_sbfe((int)lo, l, 1);
-          kh[l] = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
+          const u32 kl = (u32)__builtin_amdgcn_sbfe((int)lo, l, 1);
+          const u32 kh = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
+          blo = borrow3(C[l], kl, blo);    // C < lo
+          bhi = borrow3(kh, C[l], bhi);    // C > hi
         }
-        u32 any_m = 0u;
-        u32x4 zn[GZ];   // the added row's planes of dwords sub + 16 d, read from LDS one d ahead
+        u32 m = (blo | bhi) & valid;
+        if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) return;
+        n_slow++;
+        const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(it.tot);
+        while (m != 0u) {
+          u32 bb[4], vv[4];
 #pragma unroll
-        for (int jz = 0; jz < GZ; jz++) zn[jz] = zst[jz * 64 + sub];
+          for (int k = 0; k < 4; k++) {
+            bb[k] = m ? (u32)__builtin_ctz(m) : bb[k ? k - 1 : 0];   // exhausted: repeat the last one (max is idempotent)
+            m &= m - 1u;
+            u32 cnt = 0u;
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-          u32 Z[LZ];
-#pragma unroll
-          for (int jz = 0; jz < GZ; jz++) {
-            const u32x4 v = zn[jz];
-            Z[4 * jz + 0] = v.x; Z[4 * jz + 1] = v.y; Z[4 * jz + 2] = v.z; Z[4 * jz + 3] = v.w;
-            if (d < 3) zn[jz] = zst[jz * 64 + sub + 16 * (d + 1)];
+            for (int l = 0; l < L; l++) cnt |= ((C[l] >> bb[k]) & 1u) << l;
+            vv[k] = diag_g[cnt];
           }
-          u32 C[L];
-          if (all_overlap) {
-            // ---- C = B + (Nz - S).  Nz - S >= 0: the overlap is part of the added row ----
-            u32 T[LZ];
-            u32 bw = 0u;
 #pragma unroll
-            for (int l = 0; l < LZ; l++) {
-              if (l < kQS) {
-                T[l] = xor3(Z[l], S[l < kQS ? l : 0][d], bw);
-                bw = borrow3(Z[l], S[l < kQS ? l : 0][d], bw);
-              } else {
-                T[l] = Z[l] ^ bw;
-                bw = bw & ~Z[l];
-              }
-            }
-            u32 cy = 0u;
-#pragma unroll
-            for (int l = 0; l < L; l++) {
-              if (l < LZ) {
-                C[l] = xor3(B[l][d], T[l < LZ ? l : 0], cy);
-                cy = majority(B[l][d], T[l < LZ ? l : 0], cy);
-              } else {
-                C[l] = B[l][d] ^ cy;
-                cy = B[l][d] & cy;
-              }
-            }
-          } else {
-            // ---- some group's list is a delta list (rare): T = X - Y with (X, Y) = (Z, S) or (S, 0) per group ----
-            u32 bw = 0u, cy = 0u;
-#pragma unroll
-            for (int l = 0; l < L; l++) {
-              const u32 zl = (l < LZ) ? Z[l < LZ ? l : 0] : 0u;
-              const u32 sl = (l < kQS) ? S[l < kQS ? l : 0][d] : 0u;
-              const u32 X = mux3(zl, sl, mo);
-              const u32 Y = sl & mo;
-              const u32 T = xor3(X, Y, bw);
-              bw = borrow3(X, Y, bw);
-              C[l] = xor3(B[l][d], T, cy);
-              cy = majority(B[l][d], T, cy);
-            }
-          }
-          if constexpr (OUT) {
-            const u64 rh = (u64)a.out_first + first + j;
-            u32x4* dst = (u32x4*)(a.planes_out + (((u64)kt * (u64)a.rows_out + rh) * (u64)a.go) * 256u) + sub + 16 * d;
-#pragma unroll
-            for (int jo = 0; jo < 4; jo++) {
-              if (jo < a.go) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (4 * jo < L) v = u32x4{C[(4 * jo) % L], (4 * jo + 1 < L) ? C[(4 * jo + 1) % L] : 0u, (4 * jo + 2 < L) ? C[(4 * jo + 2) % L] : 0u,
-                                          (4 * jo + 3 < L) ? C[(4 * jo + 3) % L] : 0u};
-                dst[jo * 64] = v;
-              }
-            }
-          }
-          // ---- interval test: live permutations whose count lies outside [lo, hi] of the path's diagonal ----
-          u32 blo = 0u, bhi = 0u;
-#pragma unroll
-          for (int l = 0; l < L; l++) {
-            blo = borrow3(C[l], kl[l], blo);    // C - lo borrows  <=>  C < lo
-            bhi = borrow3(kh[l], C[l], bhi);    // hi - C borrows  <=>  C > hi
-          }
-          u32 m = blo | bhi;
-          if (tail_tile) {   // dwords sub + 16 d of the last tile: permutations past K do not exist
-            const int lv = (int)k_K - kt * 2048 - (sub + 16 * d) * 32;
-            m &= lv >= 32 ? 0xffffffffu : (lv <= 0 ? 0u : ((1u << lv) - 1u));
-          }
-          if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
-          // ---- the few permutations that can raise a maximum: rebuild each count from the planes, look it up ----
-          GCRE_QT(tl0);
-          any_m |= m;
-          const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(tot);
-          u32* nmw = nmax_lds[wave] + (sub + 16 * d);
-          while (m != 0u) {
-            u32 bb[4], vv[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              bb[k] = m ? (u32)__builtin_ctz(m) : bb[k ? k - 1 : 0];   // exhausted: repeat the last one (max is idempotent)
-              m &= m - 1u;
-              u32 cnt = 0u;
-#pragma unroll
-              for (int l = 0; l < L; l++) cnt |= ((C[l] >> bb[k]) & 1u) << l;
-              vv[k] = diag_g[cnt];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-              __hip_atomic_fetch_max(nmw + bb[k] * 64, vv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_max_u32
-          }
-          dirty = true;
-          GCRE_QT(tl1);
-          GCRE_QT_ADD(5, tl1, tl0);
+          for (int k = 0; k < 4; k++)
+            __hip_atomic_fetch_max(nm + bb[k] * 64, vv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_max_u32
         }
-        GCRE_QT(ti4);
-        GCRE_QT_ADD(4, ti4, ti3);
-#ifdef GCRE_IE_TIMING
-        tm[7] += 1;
-#endif
-        if (a.stats) {   // joined paths (of the up to four) with at least one look-up in this tile
-          const unsigned long long bal = __builtin_amdgcn_ballot_w64(any_m != 0u);
-          if (bal) {
+        dirty = true;
+      };
 #pragma unroll
-            for (u32 g2 = 0; g2 < 4; g2++)
-              if (g2 < qcnt && ((bal >> (16 * g2)) & 0xffffull)) n_slow++;
+      for (int g = 0; g < kQSegs; g++) {
+        if ((u32)g < qcnt && todo[g] != 0ull) {
+          u64 m = todo[g];
+          u32 yA[8], yB[8], ZA[LZ], ZB[LZ];
+#pragma unroll
+          for (int l = 0; l < LZ; l++) ZA[l] = ZB[l] = 0u;
+          u32 tA = (u32)__builtin_ctzll(m);
+          m &= m - 1ull;
+          Item iA = item_meta(g, tA), iB = iA;
+          item_issue(iA, tA, yA, ZA);
+          for (;;) {
+            const bool moreB = m != 0ull;
+            if (moreB) {
+              const u32 tB = (u32)__builtin_ctzll(m);
+              m &= m - 1ull;
+              iB = item_meta(g, tB);
+              item_issue(iB, tB, yB, ZB);
+            }
+            exact_f(iA, B[g], yA, ZA);
+            if (!moreB) break;
+            const bool moreA = m != 0ull;
+            if (moreA) {
+              tA = (u32)__builtin_ctzll(m);
+              m &= m - 1ull;
+              iA = item_meta(g, tA);
+              item_issue(iA, tA, yA, ZA);
+            }
+            exact_f(iB, B[g], yB, ZB);
+            if (!moreA) break;
           }
         }
       }
     }
   }
   flush_tile();
-#ifdef GCRE_IE_TIMING
-  tm[6] = __builtin_amdgcn_s_memtime() - tm_begin;
-  if (a.timing && lane == 0)
-    for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)a.timing + i, (unsigned long long)tm[i]);
-#endif
   if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
 }
 
-#define GCRE_IEQ_OR(EXPR, LL, GG)                                                  \
-  if (out) { if (rec) { EXPR(LL, GG, true, true); } else { EXPR(LL, GG, true, false); } }   \
-  else { if (rec) { EXPR(LL, GG, false, true); } else { EXPR(LL, GG, false, false); } }
+#define GCRE_IEQ_R(EXPR, LL, GG) if (rec) { EXPR(LL, GG, true); } else { EXPR(LL, GG, false); }
 
 #ifdef GCRE_IEQ_ONLY   // quick builds while tuning: one variant
-#define GCRE_IEQ(EXPR) { const int gz_ = gz; (void)gz_; (void)planes; if (out) { EXPR(10, 2, true, false); } else if (rec) { EXPR(10, 2, false, true); } else { EXPR(10, 2, false, false); } }
+#define GCRE_IEQ(EXPR) { (void)gz; (void)planes; GCRE_IEQ_R(EXPR, 10, 2) }
 #else
 #define GCRE_IEQ(EXPR)                                                     \
-  if (planes <= 8) { GCRE_IEQ_OR(EXPR, 8, 2) }                             \
+  if (planes <= 8) { GCRE_IEQ_R(EXPR, 8, 2) }                              \
   else if (planes <= 10) {                                                 \
-    if (gz <= 2) { GCRE_IEQ_OR(EXPR, 10, 2) } else { GCRE_IEQ_OR(EXPR, 10, 3) }        \
+    if (gz <= 2) { GCRE_IEQ_R(EXPR, 10, 2) } else { GCRE_IEQ_R(EXPR, 10, 3) }        \
   } else if (planes <= 12) {                                               \
-    if (gz <= 2) { GCRE_IEQ_OR(EXPR, 12, 2) } else { GCRE_IEQ_OR(EXPR, 12, 3) }        \
+    if (gz <= 2) { GCRE_IEQ_R(EXPR, 12, 2) } else { GCRE_IEQ_R(EXPR, 12, 3) }        \
   } else {                                                                 \
-    if (gz <= 2) { GCRE_IEQ_OR(EXPR, 16, 2) }                              \
-    else if (gz == 3) { GCRE_IEQ_OR(EXPR, 16, 3) }                         \
-    else { GCRE_IEQ_OR(EXPR, 16, 4) }                                      \
+    if (gz <= 2) { GCRE_IEQ_R(EXPR, 16, 2) }                               \
+    else if (gz == 3) { GCRE_IEQ_R(EXPR, 16, 3) }                          \
+    else { GCRE_IEQ_R(EXPR, 16, 4) }                                       \
   }
 #endif
 
+// quad form: method 1, pruned, no plane output (kept joins stay on k_null_ie_m1)
 hipError_t launch_null_ie_quad(const IeArgs& a, int planes, hipStream_t stream) {
   const dim3 grid((unsigned)(8 * a.waves_per_xcd / kIeWaves));
   const dim3 block(64 * kIeWaves);
   const int gz = a.gz;
-  const bool out = a.planes_out != nullptr;
   const bool rec = a.rec_slot != nullptr;
-#define GCRE_LAUNCHQ(LL, GG, OO, RR) hipLaunchKernelGGL((k_null_ie_q<LL, GG, OO, RR>), grid, block, 0, stream, a)
+#define GCRE_LAUNCHQ(LL, GG, RR) hipLaunchKernelGGL((k_null_ie_q<LL, GG, RR>), grid, block, 0, stream, a)
   GCRE_IEQ(GCRE_LAUNCHQ)
 #undef GCRE_LAUNCHQ
   return hipGetLastError();
 }
 
-int ieq_max_waves_per_cu(int planes, int gz, bool out, bool rec) {
+int ieq_max_waves_per_cu(int planes, int gz, bool rec) {
   int blocks = 0;
   hipError_t e = hipSuccess;
-#define GCRE_OCCQ(LL, GG, OO, RR) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_q<LL, GG, OO, RR>, 64 * kIeWaves, 0)
+#define GCRE_OCCQ(LL, GG, RR) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_q<LL, GG, RR>, 64 * kIeWaves, 0)
   GCRE_IEQ(GCRE_OCCQ)
 #undef GCRE_OCCQ
   if (e != hipSuccess || blocks < 1) blocks = 1;

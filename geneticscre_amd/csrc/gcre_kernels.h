@@ -142,15 +142,13 @@ struct IeArgs {
   int lad_mode;              // method-1 kernel: 0 thresholds from the running maxima, 1 look nothing up, 2 look everything up
   int ladder_stride;         // = number of table diagonals
   uint32_t mt_rows, zoff;
-  // quad form of the pruned method-1 kernel (gcre_ieq.hip): the transposed masks with every row's dwords in lane order
-  // (dword s + 16 d of a row at position 4 s + d), and the quad table: entry = first segment | (segments - 1) << 30, up to
-  // four consecutive segments of `segs` that join the same paths1 rows
-  const uint32_t* mtq;
+  // quad form of the pruned method-1 kernel (gcre_ieq.hip): entry = first segment | (segments - 1) << 30, up to four
+  // consecutive segments of `segs` that join the same paths1 rows
   const uint32_t* quads;
   int64_t quad_begin, quad_end;
 };
 hipError_t launch_null_ie_quad(const IeArgs& a, int planes, hipStream_t stream);   // gcre_ieq.hip
-int ieq_max_waves_per_cu(int planes, int gz, bool out, bool rec);
+int ieq_max_waves_per_cu(int planes, int gz, bool rec);
 hipError_t launch_fill_rec_segs(const SparseSeg* segs, int64_t nsegs, const uint32_t* r_row0, const uint32_t* r_rowz,
                                 const uint32_t* r_linfo, const uint32_t* r_lover, const uint32_t* r_slot, uint32_t* out,
                                 hipStream_t stream);
@@ -170,8 +168,7 @@ hipError_t launch_delta_fill(const uint32_t* p0, int S32, int W32p, int method, 
 hipError_t launch_row_bits(const uint32_t* rows, int64_t nrows, int S32, int W32p, uint32_t* cnt, hipStream_t stream);
 hipError_t launch_row_fill(const uint32_t* rows, int64_t nrows, int S32, int W32p, const uint64_t* off, uint32_t zoff,
                            uint32_t* idx, hipStream_t stream);
-// mtq (optional): the same rows with their dwords in the quad kernel's lane order
-hipError_t launch_build_mt(const uint32_t* masks, int W32p, int Kpad, int nkt, uint32_t mt_rows, uint32_t* mt, uint32_t* mtq,
+hipError_t launch_build_mt(const uint32_t* masks, int W32p, int Kpad, int nkt, uint32_t mt_rows, uint32_t* mt,
                            hipStream_t stream);
 
 hipError_t launch_pack_dense(const int32_t* data, int64_t nrow, int ncol, int col_major, uint64_t* rows, int S,

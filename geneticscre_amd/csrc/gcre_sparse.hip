@@ -439,7 +439,7 @@ hipError_t launch_row_fill(const uint32_t* rows, int64_t nrows, int S32, int W32
 // ------------------------------------------------------------------------------------------------
 // transposed masks: mt[kt][i][lane] bit q = mask bit of patient i under permutation kt*2048 + lane*32 + q
 // ------------------------------------------------------------------------------------------------
-__global__ void k_build_mt(const u32* masks, int W32p, int Kpad, int nkt, u32 mt_rows, u32* mt, u32* mtq) {
+__global__ void k_build_mt(const u32* masks, int W32p, int Kpad, int nkt, u32 mt_rows, u32* mt) {
   // one thread per (dword row k32 of the masks, tile, lane): a 32x32 bit transpose
   const i64 total = (i64)W32p * nkt * 64;
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
@@ -457,18 +457,16 @@ __global__ void k_build_mt(const u32* masks, int W32p, int Kpad, int nkt, u32 mt
 #pragma unroll
       for (int q = 0; q < 32; q++) v |= ((m[q] >> b) & 1u) << q;
       mt[((size_t)kt * mt_rows + (size_t)k32 * 32 + b) * 64 + lane] = v;
-      // quad kernel (gcre_ieq.hip): lane (g, s) reads dwords s, s + 16, s + 32, s + 48 of a row as one dwordx4
-      if (mtq) mtq[((size_t)kt * mt_rows + (size_t)k32 * 32 + b) * 64 + 4 * (lane & 15) + (lane >> 4)] = v;
     }
   }
 }
 
-hipError_t launch_build_mt(const uint32_t* masks, int W32p, int Kpad, int nkt, uint32_t mt_rows, uint32_t* mt, uint32_t* mtq,
+hipError_t launch_build_mt(const uint32_t* masks, int W32p, int Kpad, int nkt, uint32_t mt_rows, uint32_t* mt,
                            hipStream_t stream) {
   const i64 total = (i64)W32p * nkt * 64;
   if (total == 0) return hipSuccess;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(k_build_mt, dim3(grid), dim3(256), 0, stream, masks, W32p, Kpad, nkt, mt_rows, mt, mtq);
+  hipLaunchKernelGGL(k_build_mt, dim3(grid), dim3(256), 0, stream, masks, W32p, Kpad, nkt, mt_rows, mt);
   return hipGetLastError();
 }
 

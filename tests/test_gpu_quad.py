@@ -1,5 +1,6 @@
-"""The four-paths-per-wave form of the pruned method-1 null kernel (gcre_ieq.hip) against the CPU oracle and against
-k_null_ie_m1, through the C ABI (pytest -m gpu).  Reference semantics: src/methods.h:58-105."""
+"""The quad form of the pruned method-1 null kernel (gcre_ieq.hip: up to four segments per wave that share the added
+rows' planes) against the CPU oracle and against k_null_ie_m1, through the C ABI (pytest -m gpu).  Reference
+semantics: src/methods.h:58-105."""
 import numpy as np
 import pytest
 
@@ -37,7 +38,8 @@ def test_quad_kernel_matches_oracle_and_runs(length, n_perm, patients, warm, mon
     for name, lst in names.items():
         if name in got:
             assert_same_result(got[name], want[lst])
-    assert prof["ie_quad_launches"] > 0, prof
+    if warm == "0" or length >= 4:   # a short last level may fit the warm-up slice whole
+        assert prof["ie_quad_launches"] > 0, prof
 
 
 @pytest.mark.parametrize("table_seed", [1, 2])
@@ -58,11 +60,10 @@ def test_quad_kernel_arbitrary_table_prunes_exactly(table_seed, monkeypatch):
         assert prof["ie_quad_launches"] > 0
 
 
-@pytest.mark.parametrize("top_rate,expect_quad", [(0.08, True), (0.25, False)])
-def test_quad_and_single_path_forms_agree_on_dense_rows(top_rate, expect_quad, monkeypatch):
-    """Carrier rates up to 8 %: overlap lists of several 8-entry blocks, delta lists, 12 counter planes -- the block loop
-    of the quad kernel.  Up to 25 %: lists longer than the 56 entries it sums in registers, the launch stays on
-    k_null_ie_m1.  Same results as the oracle either way."""
+@pytest.mark.parametrize("top_rate", [0.08, 0.25])
+def test_quad_and_single_segment_forms_agree_on_dense_rows(top_rate, monkeypatch):
+    """Carrier rates up to 8 % / 25 %: overlap lists of several 8-entry blocks, delta lists, 12-16 counter planes, bound
+    filters that leave most lanes uncertain.  Same results as the oracle with the quad form and without it."""
     rng = np.random.default_rng(3)
     nc, nt = 260, 250
     p = make_problem(70, 420, nc, nt, 2100, 4, method="method1", top_k=15, seed=9)
@@ -77,7 +78,4 @@ def test_quad_and_single_path_forms_agree_on_dense_rows(top_rate, expect_quad, m
         got, prof = run_plan(p)
         for name, lst in (("1b", "lst1"), ("2", "lst2"), ("3", "lst3"), ("4", "lst4")):
             assert_same_result(got[name], want[lst])
-        if quad == "0":
-            assert prof["ie_quad_launches"] == 0
-        elif expect_quad:
-            assert prof["ie_quad_launches"] >= 2, prof   # levels 3 and 4 at least
+        assert (prof["ie_quad_launches"] > 0) == (quad == "2"), prof

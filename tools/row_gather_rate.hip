@@ -59,6 +59,47 @@ __global__ __launch_bounds__(256) void k_rows_quad(const u32* table, u32 nrows, 
   out[blockIdx.x * 256 + threadIdx.x] = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
 }
 
+// MASKED: the dword form (one 256-byte row per wave load) with only `act` lanes taking part: what the bound filter's
+// uncertain lanes issue.  Is an exec-masked wave load cheaper for the vector-memory pipe than a full one?
+__global__ __launch_bounds__(256) void k_rows_masked(const u32* table, u32 nrows, u32* out, int iters, u32 seed, int act) {
+  const int lane = threadIdx.x & 63;
+  const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6);
+  u32 s = seed ^ (wave * 2654435761u);
+  u32 acc = 0;
+  const bool on = ((lane * 37 + 11) & 63) < act;   // scattered lanes
+  for (int it = 0; it < iters; it++) {
+    u32 rows[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { s = s * 1664525u + 1013904223u; rows[j] = __builtin_amdgcn_readfirstlane((s >> 8) % nrows); }
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc ^= table[(size_t)rows[j] * 64 + lane];
+    }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+int run_masked(u32 nrows, int blocks_per_cu, int iters, int act) {
+  const size_t bytes = (size_t)nrows * 256;
+  u32 *table, *out;
+  CHECK(hipMalloc(&table, bytes)); CHECK(hipMemset(table, 1, bytes));
+  const int blocks = 256 * blocks_per_cu;
+  CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
+  hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  float ms = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL(k_rows_masked, dim3(blocks), dim3(256), 0, 0, table, nrows, out, iters, 12345u + rep, act);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    CHECK(hipEventElapsedTime(&ms, a, b));
+  }
+  const double loads = (double)blocks * 4 * iters * 16;
+  printf("masked dword rows, %2d of 64 lanes  table %6.1f MB  %2d waves/CU : %.3f ms  %.2f Gload/s  %.1f clk/load/CU @2.3GHz\n", act,
+         bytes / 1e6, blocks_per_cu * 4, ms, loads / ms / 1e6, ms * 1e-3 * 2.3e9 * 256 / loads);
+  hipFree(table); hipFree(out);
+  return 0;
+}
+
 template <int ACT>
 int run_quad(u32 nrows, int blocks_per_cu, int iters) {
   const size_t bytes = (size_t)nrows * 256;
@@ -114,6 +155,8 @@ int main() {
       if (run_quad<4>(nrows, bpc, 256)) return 1;
       if (run_quad<2>(nrows, bpc, 256)) return 1;
     }
+    for (int act : {1, 2, 4, 16, 64})
+      if (run_masked(5121u, bpc, 256, act)) return 1;
   }
   return 0;
 }
