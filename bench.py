@@ -7,9 +7,9 @@ One "step" = one pass of the hot path (the ProcessPaths join sequence, reference
 levels 1a, 1b, 2 .. path_length) over one synthetic problem whose inputs are already resident in HBM.
 For N > 1 it is launched by torch.distributed.run, one rank per GPU: every level's joined paths are sharded
 into N contiguous slices, each rank scores its slice, and the per-permutation null maxima (MAX all-reduce) and
-the top-k tables (all-gather + merge) are exchanged over RCCL.  Default "weak" scaling: the job runs the config's
-permutation count PER GPU (K = 10,000 x N at configs[2]: more GPUs buy a finer p-value floor in the same time), so the
-scores a GPU computes per pass do not depend on N; `--scaling strong` keeps K fixed instead (same results for any N).
+the top-k tables (all-gather + merge) are exchanged over RCCL.  Default "strong" scaling: every N scores the SAME
+workload (BASELINE configs[2]) with identical results; `--scaling weak` runs the config's permutation count PER GPU
+instead (K x N in total: more GPUs buy a finer p-value floor in the same time).
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -37,10 +37,36 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9        # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops/s (32-bit integer VALU)
+# wave64 VALU instructions per second the chip issues: a SIMD-32 takes 2 clocks per wave64 instruction (one wave alone: 4).
+# Measured with tools/valu_rate.hip (profiles/r02_valu_rate.txt): v_and+v_xor 117.8, v_bitop3 full adders 105-106 of 128
+# lane-ops/clk/CU with >= 2 waves per SIMD -- 0.92 / 0.83 of the nominal 256 x 4 x 2.4e9 / 2
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2.0
 ROW_LOAD_PEAK_G = 42.0                      # G wave-loads/s of random 256-B L2-resident rows (tools/row_gather_rate.hip)
 
 
-def build_inputs(cfg, seed, top_k):
+def fast_table(n_cases, n_ctrls):
+    """A cheap stand-in for the -log hypergeometric table at sizes where building the real one takes minutes
+    (tests that compare two kernels with each other, where the values do not matter but the valley shape does):
+    half the chi-square statistic of the 2 x 2 split."""
+    n = float(n_cases + n_ctrls)
+    out = np.empty((n_cases + 1, n_ctrls + 1), dtype=np.float64)
+    j = np.arange(n_ctrls + 1, dtype=np.float64)[None, :]
+    step = max(1, (1 << 21) // (n_ctrls + 1))          # ~16 MB of rows at a time: stays in cache, no 5 GB temporaries
+    for r0 in range(0, n_cases + 1, step):
+        i = np.arange(r0, min(r0 + step, n_cases + 1), dtype=np.float64)[:, None]
+        tot = i + j
+        den = tot * (n - tot)
+        np.multiply(den, 2.0 * n_cases * n_ctrls / n, out=den)
+        num = i * n_ctrls - j * n_cases
+        np.multiply(num, num, out=num)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            np.divide(num, den, out=num)
+        num[~np.isfinite(num)] = 0.0
+        out[r0:r0 + i.shape[0]] = num
+    return out
+
+
+def build_inputs(cfg, seed, top_k, table_fn=None):
     from geneticscre_amd import synth
     rng = np.random.default_rng(seed)
     g, src, trg, sign = synth.signed_network(cfg["genes"], cfg["edges"], rng)
@@ -53,10 +79,10 @@ def build_inputs(cfg, seed, top_k):
         # configs[3]/[4] scale: the numpy table builder is O(n m^2) and the host mask generator minutes -- use the native
         # table builder (gcre_values_table, no GPU needed) and let the device draw the masks (gcre_generate_perm_masks)
         from geneticscre_amd import api
-        table = api.values_table(cfg["cases"], cfg["ctrls"])
+        table = (table_fn or api.values_table)(cfg["cases"], cfg["ctrls"])
         masks = None
     else:
-        table = synth.values_table(cfg["cases"], cfg["ctrls"])
+        table = (table_fn or synth.values_table)(cfg["cases"], cfg["ctrls"])
         masks = synth.packed_case_masks(cfg["cases"], cfg["ctrls"], cfg["perms"], rng)
     prob = synth.Problem(cfg["method"], cfg["cases"], cfg["ctrls"], cfg["length"], top_k, cfg["perms"], levels,
                          data1, data2, table, np.zeros((0, 0), np.int32), seed)
@@ -188,6 +214,63 @@ def reference_baseline(prob, masks, u, n_uids, p0, p1, threads, port_res):
             "null_maxima_equal_port": same}
 
 
+def end_to_end(prob, masks, device, total_scores):
+    """What a GWASPA() user pays (reference src/wrapper.cpp:205-217): one gcre_process_paths call on a COLD context, from
+    host buffers (genotype ints, the K x n permutation matrix, the value table) to host results."""
+    from geneticscre_amd import api
+    n = prob.n_cases + prob.n_ctrls
+    W = (n + 63) // 64
+    bits = np.unpackbits(np.ascontiguousarray(masks[:, :W]).view(np.uint8), axis=1, bitorder="little")[:, :n]
+    is_case = (np.arange(n) < prob.n_cases).astype(np.uint8)
+    perm_cases = (bits == is_case[None, :]).astype(np.int32)       # 1 = label unchanged (R/Utils.R:246-262)
+    import dataclasses
+    p2 = dataclasses.replace(prob, perm_cases=perm_cases) if dataclasses.is_dataclass(prob) else prob
+    if p2 is prob:
+        prob.perm_cases = perm_cases
+    t0 = time.perf_counter()
+    out = api.process_paths(p2, device=device)
+    wall = time.perf_counter() - t0
+    lib = {k: round(v, 2) for k, v in out["profile"].items() if k.endswith("_ms")}
+    host_mb = (prob.data1.size + prob.data2.size + perm_cases.size) * 4 / 1e6 + prob.value_table.size * 8 / 1e6
+    return {"ms": wall * 1e3, "scores_per_s": total_scores / wall, "host_input_MB": host_mb,
+            "what": "cold context: gcre_create + one gcre_process_paths call from host arrays (genotype ints, K x n permutation ints, "
+                    "value table) to host results, PCIe included; never `value`",
+            "last_join_profile_ms": lib}
+
+
+def six_join_baseline(cfg, seed, top_k, level_sample, budget_s=10.0):
+    """BASELINE.md §3's CPU baseline: the full six-join sequence of the reference harness (test/harness.cpp:121-181:
+    levels 1a, 1b, 2 .. L) through the oracle port, on a network cut down until the run takes ~10 s, at
+    threads = cores and at threads = 0 (the reference's inline mode, src/join_base.cpp:170-171; fewer permutations)."""
+    import oracle
+    from geneticscre_amd import synth
+    threads = host_threads()
+    rate = float(level_sample.get("port", level_sample).get("value", 2e9))    # scores/s of the port at `threads`
+    K = cfg["perms"]
+    best = None
+    for genes, edges in ((6000, 40000), (5000, 30000), (4000, 20000), (3000, 12000), (2000, 7000), (1000, 3000)):
+        p = synth.make_problem(genes, edges, cfg["cases"], cfg["ctrls"], 0, cfg["length"], method=cfg["method"], top_k=top_k, seed=seed + 1,
+                               table=np.zeros((cfg["cases"] + 1, cfg["ctrls"] + 1)))
+        names = ["1a", "1b"] + [str(l) for l in range(2, cfg["length"] + 1)]
+        paths = sum(int(np.maximum(np.asarray(p.levels.uids[k].count), 0).sum()) for k in names)
+        best = (p, paths, genes, edges)
+        if paths * K <= rate * budget_s * 1.5:
+            break
+    p, paths, genes, edges = best
+    rng = np.random.default_rng(seed + 2)
+    p.value_table = synth.values_table(cfg["cases"], cfg["ctrls"])
+    out = {"network": f"{genes} genes / {edges} relations, {cfg['cases']}+{cfg['ctrls']} patients, path length {cfg['length']}: {paths} joined paths over six joins",
+           "code": "oracle/gcre_oracle.cpp (port of JoinExec, -O3 -march=native)"}
+    for label, nthreads, k_run in (("threads_eq_cores", threads, K), ("threads_0", 0, max(16, K // max(threads, 1)))):
+        p.iterations = k_run
+        p.perm_cases = synth.case_or_control(cfg["cases"], cfg["ctrls"], k_run, rng)
+        t0 = time.perf_counter()
+        oracle.process_paths(p, order="reference", nthreads=nthreads)
+        t = time.perf_counter() - t0
+        out[label] = {"value": paths * k_run / t, "unit": "scores/s", "threads": nthreads, "permutations": k_run, "seconds": t}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,8 +282,9 @@ def main():
     ap.add_argument("--method", default="", choices=["", "method1", "method2"], help="override the config's scoring method")
     ap.add_argument("--top-k", type=int, default=100)
     ap.add_argument("--seed", type=int, default=20261003)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = the config's permutations per GPU (K x N in total), strong = K in total")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong = the same workload for every N (K permutations in total), weak = K per GPU (K x N)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the cold one-shot gcre_process_paths measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + several ranks on one GPU is a rehearsal of the N > 1 path, not a measurement")
@@ -235,6 +319,8 @@ def main():
     perms_per_gpu = cfg["perms"]
     if args.scaling == "weak":
         cfg["perms"] *= world
+    else:
+        perms_per_gpu = None
     prob, masks = build_inputs(cfg, args.seed, args.top_k)
 
     from geneticscre_amd import api
@@ -288,7 +374,9 @@ def main():
     W = (prob.n_cases + prob.n_ctrls + 63) // 64
     M = 1 if prob.method == "method1" else 2
 
-    # roofline of the dominant kernel (k_null) on THIS rank, from HIP events on the library's stream
+    # roofline of the dominant kernel on THIS rank: time from HIP events on the library's stream (live), bytes from
+    # SURVEY.md §8(d)'s formula (live), HBM traffic and instruction counts from the newest committed PMC passes of the
+    # same workload (profiles/rNN_x_pmc.json, tools/profile_round.sh) -- labelled with the file they come from
     null_s = prof_acc.get("null_kernel_ms", 0.0) / 1e3
     launches = max(int(prof_acc.get("null_kernel_launches", 0)), 1)
     alg_bytes = prof_acc.get("null_alg_bytes", 0.0)
@@ -300,41 +388,40 @@ def main():
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
         "launches": launches, "avg_launch_ms": null_s * 1e3 / launches, "alg_bytes_per_launch": alg_bytes / launches,
     }
-    # HBM traffic per launch and the VALU instruction count per unit of work come from the committed PMC passes of
-    # this workload (profiles/rNN_x_pmc.json, tools/profile_round.sh); time and throughput are measured live
     ie = prof_acc.get("ie_launches", 0) > 0
-    pmc = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_m_pmc.json" if ie else "r01_b_pmc_traffic.json")))
-        same = pmc.get("workload") == args.config and not args.edges and not args.perms and not args.method and world == 1
-        if same and (ie or row_loads > 0):
-            roofline["traffic"] = pmc["traffic_bytes_per_null_launch"]
-            roofline["traffic_source"] = ("profiles/%s (rocprofv3 FETCH_SIZE + WRITE_SIZE of the null kernels, raw KB x 1024; "
-                                          "the count planes and lists, not in SURVEY's formula, are most of it)"
-                                          % ("r01_m_pmc.json" if ie else "r01_b_pmc_traffic.json"))
-        else:
-            pmc = pmc if ie else None
-    except (OSError, ValueError, KeyError):
-        pmc = None
+    pmc, pmc_name = None, None
+    default_run = not args.edges and not args.perms and not args.method and world == 1
+    if ie and default_run:
+        import glob
+        for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+            try:
+                d = json.load(open(cand))
+            except (OSError, ValueError):
+                continue
+            if d.get("workload") == args.config and d.get("path_tiles"):
+                pmc, pmc_name = d, os.path.basename(cand)
+                break
+    if pmc is not None:
+        roofline["traffic"] = pmc["traffic_bytes_per_null_launch"]
+        roofline["traffic_source"] = (f"profiles/{pmc_name}, collected at {pmc.get('head', '?')}: rocprofv3 FETCH_SIZE x 2 (the guide's gfx950 "
+                                      "correction for 16-B/lane loads; an upper bound for the 4-B/lane row loads) + WRITE_SIZE of the null "
+                                      "kernels, raw KB x 1024, per join; the count planes, lists and recipes -- not in SURVEY's formula -- are most of it")
     if ie:
-        # inclusion-exclusion kernel on count planes: ~100 single-cycle-per-lane-group bit instructions per joined path
-        # and 2048-permutation tile, nothing else of comparable cost -- bound by VALU issue (one wave64 VOP3 per 4 clocks
-        # per SIMD), not by HBM and not by the L2
         nkt = (K + 2047) // 2048
         tiles = sum(plan.uids[k].total_paths for k in plan.names) * nkt / max(world, 1)
-        per_tile = 100.0
+        roofline["kernel"] = ("k_null_ie_m2" if prob.method == "method2" else "k_null_ie_q / k_null_ie_m1") + " (+ warm-up slice on k_null_ie)"
+        roofline["note"] = ("north-star accounting (algorithmic HBM bytes / kernel time).  The kernels are not HBM-bound: they are bound by "
+                            "instruction issue of their VALU + SALU mix (tools/valu_rate.hip mode fulladd+s: ~0.6 of the VALU peak at 4 "
+                            "waves per SIMD) and by memory latency at 3-4 waves per SIMD; `valu` gives the fraction of the wave64 VALU "
+                            "issue peak; `launches` counts joins (one warm-up + one pruned launch each)")
         if pmc is not None:
             valu = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in pmc["kernels"].items() if k.startswith("k_null_ie"))
-            ref_tiles = 28467181.0 * 5          # joined paths x permutation tiles of the profiled run (configs[2])
-            per_tile = valu / ref_tiles if valu > 0 else per_tile
-        peak = 256 * 4 * 2.4e9 / 4.0            # wave64 VALU instructions per second the chip can issue
-        ach = per_tile * tiles * args.steps / null_s if null_s > 0 else 0.0
-        roofline["kernel"] = "%s (+ warm-up slice on k_null_ie)" % ("k_null_ie_m2" if prob.method == "method2" else "k_null_ie_m1")
-        roofline["note"] = ("north-star accounting (algorithmic HBM bytes / kernel time); the kernel is bound by VALU issue, "
-                            "see valu; `launches` counts joins (one warm-up + one pruned launch each)")
-        roofline["valu"] = {"achieved": ach, "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
-                            "instr_per_path_tile": per_tile,
-                            "source": "SQ_INSTS_VALU of the null kernels in profiles/r01_m_pmc.json / path-tiles of that run"}
+            per_tile = valu / pmc["path_tiles"]
+            ach = per_tile * tiles * args.steps / null_s if null_s > 0 else 0.0
+            roofline["valu"] = {"achieved": ach, "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instr/s", "frac": ach / VALU_PEAK_WAVE_INSTR,
+                                "instr_per_path_tile": per_tile,
+                                "source": f"SQ_INSTS_VALU of the null kernels in profiles/{pmc_name} / path-tiles of that run; peak = 256 CUs x 4 SIMDs "
+                                          "x 2.4 GHz / 2 clocks per wave64 instruction (tools/valu_rate.hip reaches 0.92 of it)"}
     elif row_loads > 0:
         # sparse bit-sliced kernel: bound by the rate at which a CU pulls random 256-byte mask rows out of L2
         # (tools/row_gather_rate.hip measures ~40 G wave-loads/s on this chip), not by HBM and not by the VALU
@@ -360,7 +447,8 @@ def main():
                         f"{K} permutations, path length {prob.path_length}, {prob.method}"
                         + (f" (weak scaling: {perms_per_gpu} permutations per GPU x {world} GPUs)" if world > 1 and args.scaling == "weak" else ""),
             "paths_per_level": {k: plan.uids[k].total_paths for k in plan.names},
-            "scores_per_step": total_scores, "top_k": top_k, "seed": args.seed,
+            "scores_per_step": total_scores, "permutations_total": K, "permutations_per_gpu": perms_per_gpu if perms_per_gpu else K,
+            "top_k": top_k, "seed": args.seed,
             "parallelism": f"paths sharded over {world} GPU(s), RCCL max-all-reduce + top-k all-gather per level",
         },
         "roofline": roofline,
@@ -368,13 +456,19 @@ def main():
         "phases_ms_per_step": {k: prof_acc.get(k, 0.0) / args.steps for k in
                                ("null_kernel_ms", "stats_kernel_ms", "select_ms", "prepare_ms", "inspect_ms", "total_ms")},
         "ie": {k: int(prof_acc.get(k, 0)) // args.steps for k in
-               ("ie_launches", "ie_overlap_lists", "ie_hinted_joins", "ie_plane_joins", "ie_lookup_tiles")},
+               ("ie_launches", "ie_quad_launches", "ie_overlap_lists", "ie_hinted_joins", "ie_plane_joins", "ie_lookup_tiles")},
     }
+    if rank == 0 and world == 1 and not args.no_end_to_end and masks is not None:
+        try:
+            line["end_to_end"] = end_to_end(prob, masks, local_rank, total_scores)
+        except Exception as e:   # reported, never required
+            line["end_to_end"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and masks is None:
         line["cpu_baseline"] = {"skipped": "device-drawn masks at this scale; the baseline is timed on configs[2]"}
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(prob, masks)
+            line["cpu_baseline"]["six_joins"] = six_join_baseline(cfg, args.seed, args.top_k, line["cpu_baseline"])
         except Exception as e:   # the baseline is reported, never required
             line["cpu_baseline"] = {"error": repr(e)}
     if rank == 0 and os.environ.get("GCRE_BENCH_DUMP"):

@@ -944,7 +944,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   const NullConfig cfg = null_config(g.method, g.K);
   std::vector<Candidate> cands;
   c->prof = gcre_profile{};
-  double select_ms = 0;
+  double select_ms = 0, select_wait_ms = 0;
   bool keep_planes_done = false;
   int64_t keep_planes_lo = 0, keep_planes_hi = 0;
   uint32_t keep_max_tot = 0;
@@ -1616,7 +1616,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (int rc2 = queue_winners(s0, nsel, win)) return rc2;
         }
         if (win.n > 0) {
-          HIP_TRY(c, hipStreamSynchronize(st));
+          const auto tw0 = std::chrono::steady_clock::now();
+          HIP_TRY(c, hipStreamSynchronize(st));   // the null kernel of this chunk: its time is not the selection's
+          select_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
           for (uint32_t i = 0; i < win.n; i++)
             cands.push_back(Candidate{key_to_score(win.key[i]), cb + s0 + (int64_t)win.sel[i], (int32_t)win.r0[i], (int32_t)win.r1[i],
                                       (int32_t)win.cases[i], (int32_t)win.ctrls[i]});
@@ -1698,7 +1700,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
 
   c->prof.null_kernel_ms = drain_events(c, c->ev_null);
   c->prof.stats_kernel_ms = drain_events(c, c->ev_stats);
-  c->prof.select_ms = select_ms;
+  c->prof.select_ms = std::max(0.0, select_ms - select_wait_ms);
   c->prof.scores = c->prof.paths * (int64_t)g.K;
   c->prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return GCRE_OK;

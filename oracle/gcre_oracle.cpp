@@ -44,6 +44,20 @@ struct gcre_o_ctx {
   std::vector<uint64_t> perm_mask;   // [width][iters], word-major / perm-minor (join_base.cpp:109)
   std::vector<double> vt;            // [(n+1)^2], padded with -1 (join_base.cpp:72)
   std::vector<double> vtmax;         // max(vt[r][c], vt[c][r]) (methods.h:110-118)
+  // Past 16k patients the padded square is gigabytes (20 GB at 50,000 patients, twice for method 2: SURVEY App. C): the
+  // supplied nrow x ncol table is kept as it came and the padding / the symmetrisation are evaluated per access --
+  // the same cells, the same values.
+  bool lazy = false;
+  int t_rows = 0, t_cols = 0;
+  std::vector<double> raw;
+  double at(size_t r, size_t q) const {
+    if (!lazy) return vt[r * size_t(tdim) + q];
+    return (r < size_t(t_rows) && q < size_t(t_cols)) ? raw[r * size_t(t_cols) + q] : -1.0;
+  }
+  double at_max(size_t r, size_t q) const {
+    if (!lazy) return vtmax[r * size_t(tdim) + q];
+    return std::max(at(r, q), at(q, r));
+  }
   bool have_table = false, have_perms = false;
 };
 
@@ -76,6 +90,18 @@ int gcre_o_vlen(const gcre_o_ctx* ctx) { return ctx->vlen; }
 int gcre_o_set_value_table(gcre_o_ctx* c, const double* tbl, int nrow, int ncol) {
   // (n+1)x(n+1), cells outside the supplied table are -1 -- join_base.cpp:67-78
   const int T = c->tdim;
+  c->lazy = T > 16384;
+  if (c->lazy) {
+    c->t_rows = std::min(T, nrow);
+    c->t_cols = std::min(T, ncol);
+    c->raw.resize(size_t(c->t_rows) * c->t_cols);
+    for (int r = 0; r < c->t_rows; r++)
+      for (int q = 0; q < c->t_cols; q++) c->raw[size_t(r) * c->t_cols + q] = tbl[size_t(r) * ncol + q];
+    c->vt.clear();
+    c->vtmax.clear();
+    c->have_table = true;
+    return 0;
+  }
   c->vt.assign(size_t(T) * T, -1.0);
   for (int r = 0; r < std::min(T, nrow); r++)
     for (int q = 0; q < std::min(T, ncol); q++) c->vt[size_t(r) * T + q] = tbl[size_t(r) * ncol + q];
@@ -190,13 +216,13 @@ struct Worker {
       for (int r = 0; r < K; r++) pc[r] += __builtin_popcountll(joined & m[r]);   // :81-82
       if (res) res[k] = joined;                                   // :84-85
     }
-    const double score = c->vt[size_t(cases) * T + ctrls];         // :90
+    const double score = c->at(size_t(cases), size_t(ctrls));         // :90
     offer(score, idx, loc, cases, ctrls, path);
     if (all_scores) { all_scores[path] = score; all_cases[path] = cases; all_ctrls[path] = ctrls; }
     const int total = cases + ctrls;
     float* nm = null_max.data();
     for (int r = 0; r < K; r++) {                                  // :96-103
-      const double p = c->vt[size_t(pc[r]) * T + (total - int(pc[r]))];
+      const double p = c->at(size_t(pc[r]), size_t(total - int(pc[r])));
       if (p > double(nm[r])) nm[r] = float(p);
     }
   }
@@ -231,7 +257,7 @@ struct Worker {
       if (res) { res[k] = bp; res[W + k] = bn; }                   // :205-208
     }
     // observed score uses vt, the null uses vtmax -- methods.h:255 vs :227
-    const double score = c->vt[size_t(case_pos) * T + ctrl_neg] + c->vt[size_t(case_neg) * T + ctrl_pos];
+    const double score = c->at(size_t(case_pos), size_t(ctrl_neg)) + c->at(size_t(case_neg), size_t(ctrl_pos));
     const int cases = int(case_pos + case_neg), ctrls = int(ctrl_pos + ctrl_neg);   // :256-257
     offer(score, idx, loc, cases, ctrls, path);
     if (all_scores) { all_scores[path] = score; all_cases[path] = cases; all_ctrls[path] = ctrls; }
@@ -240,7 +266,7 @@ struct Worker {
       const int a = int(pa[r]), b = int(pb[r]);
       const int perm_case_neg = int(total_neg) - b;
       const int perm_ctrl_neg = int(total_pos) - a;
-      const double p = c->vtmax[size_t(a) * T + perm_ctrl_neg] + c->vtmax[size_t(perm_case_neg) * T + b];
+      const double p = c->at_max(size_t(a), size_t(perm_ctrl_neg)) + c->at_max(size_t(perm_case_neg), size_t(b));
       if (p > double(nm[r])) nm[r] = float(p);
     }
   }

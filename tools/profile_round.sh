@@ -2,7 +2,8 @@
 # what profiles/ holds for a build: kernel stats (rocprofv3 --kernel-trace --stats), PMC passes (separate), bench line
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r01_d}
+TAG=${TAG:-r02_a}
+HEAD_SHA=${HEAD_SHA:-unknown}
 rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof/bench_kt.json 2> gpurun_out/prof/kt.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1 || exit 1
@@ -10,13 +11,14 @@ rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-form
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d gpurun_out/prof/sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/prof/sq2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1 || exit 1
 python3 bench.py --steps 3 --warmup 1 > gpurun_out/prof/bench.json 2> gpurun_out/prof/bench.err || exit 1
-python3 - "$TAG" <<'PY'
+python3 - "$TAG" "$HEAD_SHA" <<'PY'
 import csv, glob, collections, json, sys, shutil
-tag = sys.argv[1]
+tag, head = sys.argv[1], sys.argv[2]
 out = {"_provenance": "rocprofv3 --pmc passes (separate: FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum | SQ issue/wait | SQ instruction mix), --kernel-trace only, "
        "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline; raw counter sums over the dispatches of each kernel; FETCH/WRITE_SIZE in KB "
-       "(MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streams by up to 2x; not corrected here)",
-       "workload": "roofline", "kernels": {}}
+       "(MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of 16-B/lane streams: traffic_bytes_per_null_launch "
+       "doubles it -- exact for the plane loads, an upper bound for the 4-B/lane mask-row loads)",
+       "workload": "roofline", "head": head, "kernels": {}}
 for d in ("fetch", "tcc", "sq", "sq2"):
     for f in glob.glob(f"gpurun_out/prof/{d}/**/*counter_collection.csv", recursive=True):
         seen = collections.defaultdict(set)
@@ -32,7 +34,11 @@ fetch = sum(out["kernels"][k].get("FETCH_SIZE", 0) for k in null) * 1024
 write = sum(out["kernels"][k].get("WRITE_SIZE", 0) for k in null) * 1024
 launches = 5   # joins per pass: every join is one null "launch" in bench.py's accounting (warm-up slice + pruned kernel)
 out["null_kernels"] = null
-out["traffic_bytes_per_null_launch"] = (fetch + write) / launches
+out["traffic_bytes_per_null_launch"] = (2 * fetch + write) / launches
+out["fetch_bytes_raw"], out["write_bytes_raw"] = fetch, write
+b = json.load(open("gpurun_out/prof/bench.json"))
+K = b["config"]["permutations_total"]
+out["path_tiles"] = sum(b["config"]["paths_per_level"].values()) * ((K + 2047) // 2048)
 json.dump(out, open(f"gpurun_out/prof/{tag}_pmc.json", "w"), indent=1)
 f = glob.glob("gpurun_out/prof/kt/**/*kernel_stats.csv", recursive=True)[0]
 shutil.copy(f, f"gpurun_out/prof/{tag}_kernel_stats_roofline_steps2.csv")
