@@ -324,8 +324,10 @@ def main():
     prob, masks = build_inputs(cfg, args.seed, args.top_k)
 
     from geneticscre_amd import api
-    from geneticscre_amd.dist import exchange_level
+    from geneticscre_amd.dist import agree_window, exchange_level
     plan = api.ResidentPlan(prob, device=local_rank, packed_masks=masks, mask_seed=args.seed if masks is None else None)
+    # every rank sizes its permutation window from its own free memory: they must walk the same windows
+    plan.set_window(agree_window(plan.planned_window(), world, device=dev if (world > 1 and args.backend == "nccl") else None))
     K, top_k = prob.iterations, prob.top_k
     d_null = torch.zeros(max(K, 1), dtype=torch.float32, device=dev)
     prof_acc = {}

@@ -646,8 +646,7 @@ class ResidentPlan:
         and the concatenated null maxima."""
         K = self.problem.iterations
         if self._window is None:
-            sets = [ps.size for ps in self.kept.values()] + [ps.size for ps in self.parsed]
-            self._window = self.ex.plan_perm_window(sets) if K > 0 else 1
+            self._window = self.planned_window()
         out: Dict[str, JoinResult] = {}
         nulls: Dict[str, list] = {}
         prof: Dict[str, float] = {}
@@ -674,6 +673,27 @@ class ResidentPlan:
             r.null = np.concatenate(nulls[name]) if len(nulls[name]) > 1 else nulls[name][0]
         self.last_profile = prof
         return out
+
+    def planned_window(self) -> int:
+        """Permutations per window THIS device would choose (from its free memory, gcre_plan_perm_window).  Ranks of a
+        multi-GPU job must agree on one value before the first pass -- every (level, window) is one round of collectives --
+        see ``geneticscre_amd.dist.agree_window`` and ``set_window``."""
+        if self.problem.iterations <= 0:
+            return 1
+        sets = [ps.size for ps in self.kept.values()] + [ps.size for ps in self.parsed]
+        return self.ex.plan_perm_window(sets)
+
+    def set_window(self, perms: int) -> None:
+        """Fix the permutation window (a multiple of the 2048-permutation tile unless it covers everything)."""
+        K = max(self.problem.iterations, 1)
+        perms = int(perms)
+        self._window = K if perms >= K else max(2048, perms // 2048 * 2048)
+
+    def windows(self):
+        """[(k0, k1), ...] the passes of ``run`` will walk."""
+        K = self.problem.iterations
+        w = self._window if self._window is not None else self.planned_window()
+        return [(k0, min(K, k0 + w)) for k0 in range(0, max(K, 1), w)]
 
     def total_scores(self) -> int:
         return self.problem.iterations * sum(self.uids[k].total_paths for k in self.names)

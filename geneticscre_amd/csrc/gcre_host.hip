@@ -138,6 +138,7 @@ struct gcre_ctx {
   std::vector<PlaneBuf> plane_pool;
   // live path sets by id: a recipe names its operands by id + version, never by pointer alone
   std::unordered_map<uint64_t, const gcre_pathset*> live_sets;
+  std::vector<gcre_uids*> live_uids;   // join indices created on this context (gcre_destroy releases what is still alive)
   uint64_t next_set_id = 0;
   size_t planes_out_max = (size_t)8 << 30;   // kept sets (method 1) whose planes are larger keep a recipe only
 
@@ -770,6 +771,10 @@ struct JoinPlan {
 void free_uids(gcre_uids* u) {
   if (!u) return;
   if (u->ctx && u->ctx->stream) (void)hipStreamSynchronize(u->ctx->stream);
+  if (u->ctx) {
+    auto& v = u->ctx->live_uids;
+    v.erase(std::remove(v.begin(), v.end(), u), v.end());
+  }
   for (void* p : {(void*)u->d_path_idx, (void*)u->d_location, (void*)u->d_signs, (void*)u->d_red_index,
                   (void*)u->d_range_of, (void*)u->d_pair_range, (void*)u->d_pair_loc})
     if (p) (void)hipFree(p);
@@ -823,6 +828,7 @@ gcre_uids* make_uids(gcre_ctx* c, int path_length, const int32_t* uid_count, con
     free_uids(u);
     return nullptr;
   }
+  c->live_uids.push_back(u);
   return u;
 }
 
@@ -1795,6 +1801,14 @@ void gcre_destroy(gcre_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  // path sets and join indices the caller did not free: their rows, lists, count planes, recipes and segment tables go
+  // with the context (their handles are invalid from here on, include/gcre_hip.h)
+  while (!c->live_uids.empty()) free_uids(c->live_uids.back());
+  {
+    std::vector<const gcre_pathset*> sets;
+    for (const auto& kv : c->live_sets) sets.push_back(kv.second);
+    for (const gcre_pathset* ps : sets) gcre_pathset_free(const_cast<gcre_pathset*>(ps));
+  }
   for (void* p : {(void*)c->d_case_mask, (void*)c->d_masks, (void*)c->d_t32, (void*)c->d_dvt, (void*)c->d_dmax,
                   (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot, (void*)c->d_queue, (void*)c->d_ladder})
     if (p) (void)hipFree(p);

@@ -4,8 +4,13 @@
  *
  * Built INSIDE the R package in place of the Rcpp sources:
  *     R CMD SHLIB -o geneticsCRE.so r_shim.c -ldl
- * It needs only R's own C API (no Rcpp).  R is not installed in the build container of this repository, so
- * this file is compile-untested there; it is deliberately plain C with no logic beyond marshalling.
+ * It needs only R's own C API (no Rcpp).  R is not installed in the build container of this repository: there the
+ * file is only syntax- and type-checked against declarations of the R API entry points it uses
+ * (tests/r_api_decls/, tests/test_host_logic.py); it is deliberately plain C with no logic beyond marshalling.
+ *
+ * The unmodified R package passes doubles for several "integer" arguments (rep(1, n) sign vectors, match(...) - 1
+ * index vectors, R/ProcessPaths.R:214-256); Rcpp's IntegerVector / IntegerMatrix coerce silently, so every argument
+ * is coerced here (Rf_coerceVector keeps the dim attribute) before its data pointer is taken.
  *
  * Exported registration (identical to reference src/RcppExports.cpp:85-95):
  *     _geneticsCRE_getRels3 (4 args), _geneticsCRE_getMatchingList (3), _geneticsCRE_ProcessPaths (39)
@@ -55,6 +60,20 @@ static void load_abi(void) {
 #undef SYM
 }
 
+/* arguments as the types the C ABI wants, whatever numeric type R handed over; protected until UNPROTECT(*np) */
+static SEXP as_int(SEXP x, int* np) {
+  if (TYPEOF(x) == INTSXP) return x;
+  SEXP y = PROTECT(Rf_coerceVector(x, INTSXP));
+  (*np)++;
+  return y;
+}
+static SEXP as_real(SEXP x, int* np) {
+  if (TYPEOF(x) == REALSXP) return x;
+  SEXP y = PROTECT(Rf_coerceVector(x, REALSXP));
+  (*np)++;
+  return y;
+}
+
 /* named list "uid" -> c(count, location)  ==>  parallel key/count/location arrays (wrapper.cpp:106-112) */
 static void flatten_count_locs(SEXP lst, int32_t** keys, int32_t** counts, int32_t** locs, R_xlen_t* n) {
   SEXP names = Rf_getAttrib(lst, R_NamesSymbol);
@@ -65,14 +84,22 @@ static void flatten_count_locs(SEXP lst, int32_t** keys, int32_t** counts, int32
   for (R_xlen_t i = 0; i < *n; i++) {
     SEXP cl = VECTOR_ELT(lst, i);
     (*keys)[i] = atoi(CHAR(STRING_ELT(names, i)));      /* stoi(uid), wrapper.cpp:111 */
-    (*counts)[i] = INTEGER(cl)[0];
-    (*locs)[i] = INTEGER(cl)[1];
+    if (XLENGTH(cl) < 2) Rf_error("geneticsCRE: count_locs entries must be c(count, location)");
+    if (TYPEOF(cl) == INTSXP) {
+      (*counts)[i] = INTEGER(cl)[0];
+      (*locs)[i] = INTEGER(cl)[1];
+    } else {                                            /* c(0, -1) built from doubles (R/PathMethods.R:146-148) */
+      (*counts)[i] = (int32_t)Rf_asReal(cl);
+      (*locs)[i] = (int32_t)REAL(Rf_coerceVector(cl, REALSXP))[1];
+    }
   }
 }
 
 /* assemble_uids (wrapper.cpp:99-140) for one level */
-static void fill_level(gcre_level* lv, SEXP trg_uids, SEXP count_locs, SEXP signs) {
+static void fill_level(gcre_level* lv, SEXP trg_uids, SEXP count_locs, SEXP signs, int* np) {
   int32_t *keys, *counts, *locs;
+  trg_uids = as_int(trg_uids, np);
+  signs = as_int(signs, np);
   R_xlen_t nk, n = XLENGTH(trg_uids);
   flatten_count_locs(count_locs, &keys, &counts, &locs, &nk);
   int32_t* oc = (int32_t*)R_alloc(n ? n : 1, sizeof(int32_t));
@@ -130,6 +157,7 @@ SEXP _geneticsCRE_ProcessPaths(
     SEXP num_cases, SEXP num_ctrls, SEXP top_k, SEXP iterations, SEXP perm_cases, SEXP method, SEXP path_length,
     SEXP nthreads) {
   (void)src1; (void)src1b; (void)src2; (void)src3; (void)src4; (void)src5; (void)nthreads;
+  int np = 0;   /* coerced copies, released together */
   load_abi();
   const int nc = Rf_asInteger(num_cases), nt = Rf_asInteger(num_ctrls), K = Rf_asInteger(iterations);
   /* "method1" -> 1, anything else -> 2 (JoinExec::to_method, gcre.h:125-133) */
@@ -137,28 +165,34 @@ SEXP _geneticsCRE_ProcessPaths(
 
   gcre_pp_input in;
   memset(&in, 0, sizeof in);
-  fill_level(&in.level[0], trg1, cl1, sg1);
-  fill_level(&in.level[1], trg1b, cl1b, sg1b);
-  fill_level(&in.level[2], trg2, cl2, sg2);
-  fill_level(&in.level[3], trg3, cl3, sg3);
-  fill_level(&in.level[4], trg4, cl4, sg4);
-  fill_level(&in.level[5], trg5, cl5, sg5);
+  fill_level(&in.level[0], trg1, cl1, sg1, &np);
+  fill_level(&in.level[1], trg1b, cl1b, sg1b, &np);
+  fill_level(&in.level[2], trg2, cl2, sg2, &np);
+  fill_level(&in.level[3], trg3, cl3, sg3, &np);
+  fill_level(&in.level[4], trg4, cl4, sg4, &np);
+  fill_level(&in.level[5], trg5, cl5, sg5, &np);
   SEXP inds[4] = {inds1, inds1b, inds2, inds3};
   for (int i = 0; i < 4; i++) {
+    inds[i] = as_int(inds[i], &np);
     in.data_inds[i] = INTEGER(inds[i]);
     in.n_data_inds[i] = XLENGTH(inds[i]);
   }
-  in.data1 = INTEGER(data1);
+  if (Rf_ncols(data1) != nc + nt || Rf_ncols(data2) != nc + nt)
+    Rf_error("geneticsCRE: data matrices must have num_cases + num_ctrls columns");
   in.data1_rows = Rf_nrows(data1);
-  in.data2 = INTEGER(data2);
   in.data2_rows = Rf_nrows(data2);
+  in.data1 = INTEGER(as_int(data1, &np));
+  in.data2 = INTEGER(as_int(data2, &np));
   in.data_col_major = 1;                                /* R matrices are column-major (copy_r, wrapper.cpp:78-96) */
-  in.value_table = REAL(value_table);
   in.vt_rows = Rf_nrows(value_table);
   in.vt_cols = Rf_ncols(value_table);
+  in.value_table = REAL(as_real(value_table, &np));
   in.vt_col_major = 1;
-  in.perm_cases = XLENGTH(perm_cases) ? INTEGER(perm_cases) : NULL;   /* matrix(0,0,0) when n_permutations == 0 */
-  in.perm_rows = XLENGTH(perm_cases) ? Rf_nrows(perm_cases) : 0;
+  if (XLENGTH(perm_cases)) {                            /* matrix(0,0,0) when n_permutations == 0 */
+    if (Rf_ncols(perm_cases) != nc + nt) Rf_error("geneticsCRE: perm_cases must have num_cases + num_ctrls columns");
+    in.perm_rows = Rf_nrows(perm_cases);
+    in.perm_cases = INTEGER(as_int(perm_cases, &np));
+  }
   in.perm_col_major = 1;
   in.path_length = Rf_asInteger(path_length);
 
@@ -173,6 +207,7 @@ SEXP _geneticsCRE_ProcessPaths(
     G.destroy(ctx);
     Rf_error("geneticsCRE: %s", msg);
   }
+  G.destroy(ctx);   /* the results are plain host arrays: nothing below (R allocations may longjmp) holds the device */
 
   /* list(lst1 = ..., ..., lst5 = ...); levels above path_length stay NULL (wrapper.cpp:223) */
   SEXP out = PROTECT(Rf_allocVector(VECSXP, 5));
@@ -186,13 +221,16 @@ SEXP _geneticsCRE_ProcessPaths(
     }
   }
   Rf_setAttrib(out, R_NamesSymbol, nms);
-  G.destroy(ctx);
-  UNPROTECT(2);
+  UNPROTECT(2 + np);
   return out;
 }
 
 /* getMatchingList (wrapper.cpp:60-69): named list uid -> c(count, location) */
 SEXP _geneticsCRE_getMatchingList(SEXP uids, SEXP counts, SEXP location) {
+  int np = 0;
+  uids = as_int(uids, &np);
+  counts = as_int(counts, &np);
+  location = as_int(location, &np);
   const R_xlen_t n = XLENGTH(uids);
   SEXP out = PROTECT(Rf_allocVector(VECSXP, n));
   SEXP nms = PROTECT(Rf_allocVector(STRSXP, n));
@@ -207,13 +245,17 @@ SEXP _geneticsCRE_getMatchingList(SEXP uids, SEXP counts, SEXP location) {
     UNPROTECT(1);
   }
   Rf_setAttrib(out, R_NamesSymbol, nms);
-  UNPROTECT(2);
+  UNPROTECT(2 + np);
   return out;
 }
 
 /* getRels3 (wrapper.cpp:18-48): data.frame(srcuid, trguid, sign, trguid2, sign2), one row per 2-edge walk */
 SEXP _geneticsCRE_getRels3(SEXP srcuid, SEXP trguid, SEXP sign, SEXP count_locs) {
   load_abi();
+  int np = 0;
+  srcuid = as_int(srcuid, &np);
+  trguid = as_int(trguid, &np);
+  sign = as_int(sign, &np);
   const R_xlen_t n = XLENGTH(trguid);
   int32_t *keys, *counts, *locs;
   R_xlen_t nk;
@@ -247,7 +289,7 @@ SEXP _geneticsCRE_getRels3(SEXP srcuid, SEXP trguid, SEXP sign, SEXP count_locs)
   INTEGER(rn)[1] = -(int)total;
   Rf_setAttrib(df, R_RowNamesSymbol, rn);
   Rf_setAttrib(df, R_ClassSymbol, Rf_mkString("data.frame"));
-  UNPROTECT(8);
+  UNPROTECT(8 + np);
   return df;
 }
 

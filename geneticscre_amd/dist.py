@@ -67,3 +67,16 @@ def exchange_level(scores, src, trg, cases, ctrls, null_tensor, top_k: int, worl
     else:
         allrows = mine
     return merge_topk(allrows.cpu().numpy(), top_k)
+
+
+def agree_window(local_window: int, world: int, device=None) -> int:
+    """One permutation window for every rank: the smallest any rank planned (MIN all-reduce).  Each rank sizes its
+    window from ITS free device memory (gcre_plan_perm_window), and every (level, window) pair is one MAX all-reduce plus
+    one all-gather: ranks that walked different window lists would issue collectives of different sizes and counts."""
+    if world <= 1:
+        return int(local_window)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(local_window)], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())

@@ -88,7 +88,7 @@ typedef struct {
 
 /* ---- context: JoinExec::JoinExec, src/join_base.cpp:37-59.  method 1 = unsigned, 2 = signed. ---- */
 gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int device);
-void gcre_destroy(gcre_ctx* ctx);
+void gcre_destroy(gcre_ctx* ctx);   /* also releases every path set and uids object still alive on the context: their handles die with it */
 const char* gcre_last_error(const gcre_ctx* ctx);   /* ctx may be NULL: error of the last failed gcre_create */
 int gcre_abi_version(void);
 

@@ -177,6 +177,40 @@ def test_two_rank_exchange_over_gloo(method, tmp_path):
     assert open(tmp_path / "rank0.ok").read() == "1" and open(tmp_path / "rank1.ok").read() == "1"
 
 
+def _window_main(rank, world, port, tmp):
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    # each rank planned a different window from "its" free memory
+    local = [6 * 2048, 3 * 2048][rank]
+    w = dist.agree_window(local, world)
+    K = 20_000
+    wins = [(k0, min(K, k0 + w)) for k0 in range(0, K, w)]
+    open(os.path.join(tmp, f"win{rank}.txt"), "w").write(repr(wins))
+    tdist.destroy_process_group()
+
+
+def test_ranks_with_different_plans_walk_the_same_windows(tmp_path):
+    """Every (level, window) is one round of collectives (bench.py on_level): ranks whose gcre_plan_perm_window results
+    differ must still walk identical window lists -- the smallest plan wins (dist.agree_window, MIN all-reduce)."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_window_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = open(tmp_path / "win0.txt").read(), open(tmp_path / "win1.txt").read()
+    assert a == b and a.startswith("[(0, 6144), (6144, 12288)")
+
+
+def test_r_shim_is_valid_c_against_the_r_api_declarations():
+    """R is not in this image: the .Call shim is syntax- and type-checked against declarations of the R API functions it
+    uses (tests/r_api_decls, signatures from "Writing R Extensions") and the real C ABI header."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types",
+                        "-Werror=int-conversion", "-I", os.path.join(root, "tests", "r_api_decls"), "-I", os.path.join(root, "include"),
+                        os.path.join(root, "geneticscre_amd", "csrc", "r_shim.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_native_level_tables_equal_python_restatement(seed):
     """gcre_build_levels (C++) == uids.build_level_tables (numpy) == the R construction, on random signed networks."""
