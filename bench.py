@@ -72,7 +72,7 @@ def build_inputs(cfg, seed, top_k, table_fn=None):
     g, src, trg, sign = synth.signed_network(cfg["genes"], cfg["edges"], rng)
     levels = synth.build_level_tables(g, src, trg, sign)
     n = cfg["cases"] + cfg["ctrls"]
-    data1 = synth.variant_matrix(g, n, rng)
+    data1 = synth.variant_matrix(g, n, rng, fixed_rate=float(cfg.get("carrier_rate", 0.0)))
     data2 = data1[levels.uids["1b"].src]
     big = n * cfg["perms"] > 2_000_000_000 or n > 20000 or cfg["perms"] > 20000
     if big:
@@ -279,6 +279,8 @@ def main():
     ap.add_argument("--config", default="roofline", choices=sorted(CONFIGS))
     ap.add_argument("--edges", type=int, default=0, help="override the synthetic network's edge count")
     ap.add_argument("--perms", type=int, default=0)
+    ap.add_argument("--carrier-rate", type=float, default=0.0,
+                    help="sensitivity sweep: every gene at this carrier rate instead of 0.05 * U^3 (mean 1.25 %%)")
     ap.add_argument("--method", default="", choices=["", "method1", "method2"], help="override the config's scoring method")
     ap.add_argument("--top-k", type=int, default=100)
     ap.add_argument("--seed", type=int, default=20261003)
@@ -316,6 +318,8 @@ def main():
         cfg["edges"] = args.edges
     if args.perms:
         cfg["perms"] = args.perms
+    if args.carrier_rate:
+        cfg["carrier_rate"] = args.carrier_rate
     perms_per_gpu = cfg["perms"]
     if args.scaling == "weak":
         cfg["perms"] *= world
@@ -392,7 +396,7 @@ def main():
     }
     ie = prof_acc.get("ie_launches", 0) > 0
     pmc, pmc_name = None, None
-    default_run = not args.edges and not args.perms and not args.method and world == 1
+    default_run = not args.edges and not args.perms and not args.method and not args.carrier_rate and world == 1
     if ie and default_run:
         import glob
         for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
@@ -447,6 +451,7 @@ def main():
             "workload": f"BASELINE configs[{cfg['idx']}] '{args.config}': synthetic STRINGdb-shaped signed network, "
                         f"{cfg['genes']} genes / {cfg['edges']} relations, {prob.n_cases}+{prob.n_ctrls} patients, "
                         f"{K} permutations, path length {prob.path_length}, {prob.method}"
+                        + (f", every gene at {args.carrier_rate:.3%} carriers" if args.carrier_rate else "")
                         + (f" (weak scaling: {perms_per_gpu} permutations per GPU x {world} GPUs)" if world > 1 and args.scaling == "weak" else ""),
             "paths_per_level": {k: plan.uids[k].total_paths for k in plan.names},
             "scores_per_step": total_scores, "permutations_total": K, "permutations_per_gpu": perms_per_gpu if perms_per_gpu else K,

@@ -75,7 +75,8 @@ class gcre_pp_input(ctypes.Structure):
                 ("value_table", ctypes.c_void_p), ("vt_rows", ctypes.c_int), ("vt_cols", ctypes.c_int),
                 ("vt_col_major", ctypes.c_int),
                 ("perm_cases", ctypes.c_void_p), ("perm_rows", ctypes.c_int), ("perm_col_major", ctypes.c_int),
-                ("path_length", ctypes.c_int)]
+                ("path_length", ctypes.c_int), ("shard_rank", ctypes.c_int), ("shard_world", ctypes.c_int),
+                ("window_perms", ctypes.c_int)]
 
 
 # every symbol include/gcre_hip.h declares; tests check that the library exports all of them
@@ -87,7 +88,7 @@ EXPORTS = [
     "gcre_uids_total_paths", "gcre_uids_free", "gcre_join_uids", "gcre_get_profile",
     "gcre_process_paths", "gcre_resolve_count_locs", "gcre_build_levels", "gcre_levels_free", "gcre_values_table",
     "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask", "gcre_uids_set_reduced",
-    "gcre_set_perm_window", "gcre_plan_perm_window",
+    "gcre_set_perm_window", "gcre_plan_perm_window", "gcre_process_paths_devices",
 ]
 
 
@@ -476,6 +477,58 @@ def values_table(n_cases: int, n_ctrls: int) -> np.ndarray:
     if rc != GCRE_OK:
         raise ValueError("bad table dimensions")
     return out
+
+
+def _pp_input(problem, keep):
+    """gcre_pp_input for a synth.Problem; numpy buffers are appended to ``keep`` (they must outlive the call)."""
+    def arr(a, dt):
+        b = np.ascontiguousarray(a, dtype=dt)
+        keep.append(b)
+        return b
+
+    inp = gcre_pp_input()
+    for i, name in enumerate(["1a", "1b", "2", "3", "4", "5"]):
+        u = problem.levels.uids[name]
+        c, l, s = arr(u.count, np.int32), arr(u.location, np.int64), arr(u.signs, np.int32)
+        inp.level[i] = gcre_level(_ptr(c), _ptr(l), len(c), _ptr(s), len(s))
+    for i, name in enumerate(["1a", "1b", "2", "3"]):
+        d = arr(problem.levels.data_inds[name], np.int32)
+        inp.data_inds[i], inp.n_data_inds[i] = _ptr(d), len(d)
+    d1, d2 = arr(problem.data1, np.int32), arr(problem.data2, np.int32)
+    inp.data1, inp.data1_rows, inp.data2, inp.data2_rows, inp.data_col_major = _ptr(d1), d1.shape[0], _ptr(d2), d2.shape[0], 0
+    vt = arr(problem.value_table, np.float64)
+    inp.value_table, inp.vt_rows, inp.vt_cols, inp.vt_col_major = _ptr(vt), vt.shape[0], vt.shape[1], 0
+    pc = arr(problem.perm_cases, np.int32)
+    inp.perm_cases = _ptr(pc) if pc.size else None
+    inp.perm_rows, inp.perm_col_major = (pc.shape[0] if pc.ndim == 2 else 0), 0
+    inp.path_length = int(problem.path_length)
+    return inp
+
+
+def process_paths_devices(problem, devices=None) -> Dict[str, object]:
+    """ProcessPaths on several GPUs of the node from this one process (gcre_process_paths_devices): one context and host
+    thread per entry of ``devices`` (None: every visible device; an id may repeat), joined paths sharded, maxima and top-k
+    tables merged.  Bit-identical to ``process_paths`` for any device list."""
+    lib = load_library()
+    lib.gcre_process_paths_devices.restype = ctypes.c_int
+    lib.gcre_process_paths_devices.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_char_p, ctypes.c_size_t]
+    keep = []
+    inp = _pp_input(problem, keep)
+    outs = (gcre_result * 5)()
+    err = ctypes.create_string_buffer(512)
+    dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+    rc = lib.gcre_process_paths_devices(1 if problem.method == "method1" else 2, int(problem.n_cases), int(problem.n_ctrls),
+                                        int(problem.iterations), int(problem.top_k), _ptr(dev) if dev is not None else None,
+                                        0 if dev is None else len(dev), ctypes.byref(inp), outs, err, len(err))
+    if rc != GCRE_OK:
+        msg = err.value.decode() or f"gcre error {rc}"
+        if rc == GCRE_ERR_RANGE or "out of range" in msg:
+            raise IndexError(msg)
+        if rc == GCRE_ERR_ASSERT or "assertion" in msg:
+            raise ValueError(msg)
+        raise GcreError(msg)
+    return {f"lst{i + 1}": (None if outs[i].n < 0 else _take_result(lib, outs[i])) for i in range(5)}
 
 
 def process_paths(problem, device: int = 0, exec_: Optional[JoinExec] = None) -> Dict[str, object]:

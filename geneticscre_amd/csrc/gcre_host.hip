@@ -8,6 +8,7 @@
 #include "gcre_kernels.h"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -2317,6 +2318,11 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       if (in_range && gcre_uids_set_reduced(u, red, red_index, n_red) != GCRE_OK) return c->last_code;
     }
     JoinPlan jp{u, p0, p1, res, false, 0, 0, nullptr};
+    if (in->shard_world > 1) {   // one device of several: its slice of the joined paths, every kept row
+      jp.sharded = true;
+      jp.shard_begin = u->total * in->shard_rank / in->shard_world;
+      jp.shard_end = u->total * (in->shard_rank + 1) / in->shard_world;
+    }
     gcre_result tmp;
     int r = run_join(c, jp, &tmp);
     if (r != GCRE_OK) { gcre_result_free(&tmp); return r; }
@@ -2343,7 +2349,9 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     if (lv != 1) set_rows.push_back(total_paths(in->level[lv]));
   const int Kall = c->g.K;
   int win = std::max(1, gcre_plan_perm_window(c, set_rows.data(), (int)set_rows.size()));
-  if (Kall > kSparseTile && sparse_enabled(c)) {
+  if (in->window_perms > 0) {
+    win = in->window_perms >= Kall ? std::max(Kall, 1) : std::max(kSparseTile, in->window_perms / kSparseTile * kSparseTile);
+  } else if (Kall > kSparseTile && sparse_enabled(c)) {
     // A context without a pooled plane buffer of the full size (the R shim makes a fresh context per call, as the
     // reference does) has to hipMalloc the planes: ~40 ms per GB here, 3 KB per kept row and tile.  Against ~25 ms of
     // repeated inspector work per extra window, few tiles per window win: w* = sqrt(25 ms * tiles / (ms per tile)).
@@ -2472,6 +2480,124 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
   return GCRE_OK;
 #undef PP_REQUIRE
 #undef PP_TRY
+}
+
+// ---- several devices, one process (include/gcre_hip.h) ----
+int gcre_process_paths_devices(int method, int n_cases, int n_ctrls, int iterations, int top_k, const int* devices,
+                               int n_devices, const gcre_pp_input* in, gcre_result out[5], char* err, size_t errlen) {
+  auto say = [&](const std::string& m) {
+    if (err && errlen) std::snprintf(err, errlen, "%s", m.c_str());
+  };
+  if (!in || !out) { say("bad arguments"); return GCRE_ERR_ARG; }
+  for (int i = 0; i < 5; i++) { std::memset(&out[i], 0, sizeof out[i]); out[i].n = -1; }
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) { say("no HIP device: libgcre_hip has no CPU fallback"); return GCRE_ERR_DEVICE; }
+  std::vector<int> dev;
+  if (n_devices <= 0) n_devices = visible;
+  for (int i = 0; i < n_devices; i++) dev.push_back(devices ? devices[i] : i % visible);
+  const int N = (int)dev.size();
+  // contexts first (one per device), so that every device can be asked for its window before anybody starts
+  std::vector<gcre_ctx*> ctx((size_t)N, nullptr);
+  int rc = GCRE_OK;
+  for (int r = 0; r < N && rc == GCRE_OK; r++) {
+    ctx[(size_t)r] = gcre_create(method, n_cases, n_ctrls, iterations, dev[(size_t)r]);
+    if (!ctx[(size_t)r]) { say(gcre_last_error(nullptr)); rc = GCRE_ERR_DEVICE; break; }
+    ctx[(size_t)r]->quiet = ctx[(size_t)r]->quiet || r > 0;   // the reference's progress lines once
+    rc = gcre_set_top_k(ctx[(size_t)r], top_k);
+    if (rc != GCRE_OK) say(gcre_last_error(ctx[(size_t)r]));
+  }
+  int window = 0;
+  if (rc == GCRE_OK && N > 1 && iterations > 0) {
+    // the smallest window any device plans: all of them walk the same windows (their maxima are merged per window)
+    std::vector<int64_t> set_rows = {in->data1_rows, in->data2_rows};
+    for (int lv = 0; lv < 4 && lv <= in->path_length; lv++)
+      if (lv != 1) {
+        int64_t t = 0;
+        for (int64_t i = 0; i < in->level[lv].n_uids; i++) t += std::max(in->level[lv].uid_count[i], 0);
+        set_rows.push_back(t);
+      }
+    window = iterations;
+    for (int r = 0; r < N; r++) {
+      (void)hipSetDevice(dev[(size_t)r]);
+      window = std::min(window, std::max(1, gcre_plan_perm_window(ctx[(size_t)r], set_rows.data(), (int)set_rows.size())));
+    }
+  }
+  std::vector<std::array<gcre_result, 5>> part((size_t)N);
+  std::vector<int> rcs((size_t)N, GCRE_OK);
+  if (rc == GCRE_OK) {
+    auto work = [&](int r) {
+      gcre_pp_input mine = *in;
+      mine.shard_rank = N > 1 ? r : 0;
+      mine.shard_world = N > 1 ? N : 0;
+      mine.window_perms = N > 1 ? window : in->window_perms;
+      rcs[(size_t)r] = gcre_process_paths(ctx[(size_t)r], &mine, part[(size_t)r].data());
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < N; r++) th.emplace_back(work, r);
+    work(0);
+    for (auto& t : th) t.join();
+    for (int r = 0; r < N; r++)
+      if (rcs[(size_t)r] != GCRE_OK && rc == GCRE_OK) {
+        rc = rcs[(size_t)r];
+        say("device " + std::to_string(dev[(size_t)r]) + ": " + gcre_last_error(ctx[(size_t)r]));
+      }
+  }
+  if (rc == GCRE_OK) {
+    // merge_scores / format_result (methods.h:25-39, join_base.cpp:138-154) across devices: f32 MAX of the maxima (exact
+    // for any sharding: f32 max is associative, every device holds f32-rounded values), best top_k of all tables with the
+    // canonical tie rule (smaller joined-path ordinal = smaller (idx, loc)), the sentinel when fewer than top_k exist
+    for (int lv = 0; lv < 5; lv++) {
+      if (part[0][(size_t)lv].n < 0) continue;
+      gcre_result& o = out[lv];
+      const int K = part[0][(size_t)lv].n_perm;
+      o.n_perm = K;
+      o.null_max = (float*)std::calloc((size_t)std::max(K, 1), sizeof(float));
+      std::vector<Candidate> cands;
+      for (int r = 0; r < N; r++) {
+        const gcre_result& p = part[(size_t)r][(size_t)lv];
+        for (int k = 0; k < K; k++) o.null_max[k] = std::max(o.null_max[k], p.null_max[k]);
+        for (int i = 0; i < p.n; i++)
+          if (p.src[i] >= 0) cands.push_back(Candidate{p.scores[i], ((int64_t)p.src[i] << 32) | (uint32_t)p.trg[i], p.src[i], p.trg[i], p.cases[i], p.ctrls[i]});
+      }
+      std::sort(cands.begin(), cands.end(), [](const Candidate& a, const Candidate& b) {
+        if (a.score != b.score) return a.score > b.score;
+        return a.path < b.path;
+      });
+      const size_t keepn = std::min(cands.size(), (size_t)top_k);
+      const bool with_sentinel = cands.size() < (size_t)top_k;
+      const size_t n_out = keepn + (with_sentinel ? 1 : 0);
+      o.n = (int32_t)n_out;
+      o.scores = (double*)std::calloc(std::max<size_t>(n_out, 1), sizeof(double));
+      o.src = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+      o.trg = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+      o.cases = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+      o.ctrls = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+      size_t w = 0;
+      if (with_sentinel) {
+        o.scores[w] = -std::numeric_limits<double>::infinity();
+        o.src[w] = o.trg[w] = -1;
+        w++;
+      }
+      for (size_t i = keepn; i-- > 0;) {
+        o.scores[w] = cands[i].score;
+        o.src[w] = cands[i].src;
+        o.trg[w] = cands[i].trg;
+        o.cases[w] = cands[i].cases;
+        o.ctrls[w] = cands[i].ctrls;
+        w++;
+      }
+    }
+  }
+  for (int r = 0; r < N; r++) {
+    if (rcs[(size_t)r] == GCRE_OK)
+      for (int lv = 0; lv < 5; lv++)
+        if (part[(size_t)r][(size_t)lv].n >= 0 || part[(size_t)r][(size_t)lv].null_max) gcre_result_free(&part[(size_t)r][(size_t)lv]);
+    if (ctx[(size_t)r]) {
+      (void)hipSetDevice(dev[(size_t)r]);
+      gcre_destroy(ctx[(size_t)r]);
+    }
+  }
+  return rc;
 }
 
 }  // extern "C"

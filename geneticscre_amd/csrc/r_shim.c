@@ -30,11 +30,7 @@
 /* ---- the C ABI, resolved at first use ---------------------------------------------------------- */
 static struct {
   void* handle;
-  gcre_ctx* (*create)(int, int, int, int, int);
-  void (*destroy)(gcre_ctx*);
-  const char* (*last_error)(const gcre_ctx*);
-  int (*set_top_k)(gcre_ctx*, int);
-  int (*process_paths)(gcre_ctx*, const gcre_pp_input*, gcre_result[5]);
+  int (*process_paths_devices)(int, int, int, int, int, const int*, int, const gcre_pp_input*, gcre_result[5], char*, size_t);
   void (*result_free)(gcre_result*);
   int (*resolve)(const int32_t*, int64_t, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t*, int64_t*);
 } G;
@@ -50,11 +46,7 @@ static void load_abi(void) {
     *(void**)(&G.field) = dlsym(G.handle, name);                     \
     if (!G.field) Rf_error("geneticsCRE: %s lacks %s", path, name);  \
   } while (0)
-  SYM(create, "gcre_create");
-  SYM(destroy, "gcre_destroy");
-  SYM(last_error, "gcre_last_error");
-  SYM(set_top_k, "gcre_set_top_k");
-  SYM(process_paths, "gcre_process_paths");
+  SYM(process_paths_devices, "gcre_process_paths_devices");
   SYM(result_free, "gcre_result_free");
   SYM(resolve, "gcre_resolve_count_locs");
 #undef SYM
@@ -196,18 +188,22 @@ SEXP _geneticsCRE_ProcessPaths(
   in.perm_col_major = 1;
   in.path_length = Rf_asInteger(path_length);
 
-  gcre_ctx* ctx = G.create(m, nc, nt, K, 0);
-  if (!ctx) Rf_error("geneticsCRE: %s", G.last_error(NULL));
+  /* Every GPU of the node by default, like the reference takes `nthreads` cores (wrapper.cpp:189): GCRE_DEVICES = "all"
+   * or a comma-separated list of device ids ("0" = the one-GPU behaviour).  The call creates and releases its contexts
+   * itself: nothing native is alive when an R error (longjmp) can happen below. */
+  int devs[64], ndev = 0;
+  const char* dl = getenv("GCRE_DEVICES");
+  if (dl && strcmp(dl, "all") != 0)
+    for (const char* q = dl; *q && ndev < 64;) {
+      devs[ndev++] = atoi(q);
+      q = strchr(q, ',');
+      if (!q) break;
+      q++;
+    }
   gcre_result res[5];
-  int rc = G.set_top_k(ctx, Rf_asInteger(top_k));
-  if (rc == GCRE_OK) rc = G.process_paths(ctx, &in, res);
-  if (rc != GCRE_OK) {                                  /* release native resources BEFORE the longjmp of Rf_error */
-    char msg[512];
-    snprintf(msg, sizeof msg, "%s", G.last_error(ctx));
-    G.destroy(ctx);
-    Rf_error("geneticsCRE: %s", msg);
-  }
-  G.destroy(ctx);   /* the results are plain host arrays: nothing below (R allocations may longjmp) holds the device */
+  char msg[512] = "";
+  const int rc = G.process_paths_devices(m, nc, nt, K, Rf_asInteger(top_k), ndev ? devs : NULL, ndev, &in, res, msg, sizeof msg);
+  if (rc != GCRE_OK) Rf_error("geneticsCRE: %s", msg[0] ? msg : "gcre_process_paths_devices failed");
 
   /* list(lst1 = ..., ..., lst5 = ...); levels above path_length stay NULL (wrapper.cpp:223) */
   SEXP out = PROTECT(Rf_allocVector(VECSXP, 5));

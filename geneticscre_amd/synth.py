@@ -72,9 +72,14 @@ def case_or_control(n_cases: int, n_ctrls: int, n_perm: int, rng: np.random.Gene
     return out
 
 
-def variant_matrix(n_genes: int, n_patients: int, rng: np.random.Generator, threshold: float = 0.05) -> np.ndarray:
-    """genes x patients 0/1 int32, per-gene carrier rate heavy at the rare end, never above ``threshold``."""
+def variant_matrix(n_genes: int, n_patients: int, rng: np.random.Generator, threshold: float = 0.05,
+                   fixed_rate: float = 0.0) -> np.ndarray:
+    """genes x patients 0/1 int32, per-gene carrier rate heavy at the rare end, never above ``threshold``.
+    ``fixed_rate`` > 0: every gene at that carrier rate (the sensitivity sweep of profiles/: how the kernels hold up when
+    every gene sits at 1 %, 2.5 % or the 5 % admission limit of R/Utils.R:185-188)."""
     rate = threshold * rng.random(n_genes) ** 3
+    if fixed_rate > 0:
+        rate = np.full(n_genes, min(fixed_rate, threshold))
     data = (rng.random((n_genes, n_patients)) < rate[:, None]).astype(np.int32)
     cap = int(threshold * (n_patients + 1))            # freqs <= threshold * ncol(df), Utils.R:185-187
     for g in np.flatnonzero(data.sum(axis=1) > cap):

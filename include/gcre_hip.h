@@ -17,6 +17,7 @@
 #ifndef GCRE_HIP_H
 #define GCRE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -183,10 +184,25 @@ typedef struct {
                                   * holds (gcre_generate_perm_masks / gcre_set_perm_masks), an error if it has none */
   int perm_rows, perm_col_major;
   int path_length;               /* 1..5 */
+  /* one device of several (gcre_process_paths_devices fills these; 0 / 0 / 0 = the whole job on this context): the
+   * context scores joined-path ordinals [P * shard_rank / shard_world, P * (shard_rank + 1) / shard_world) of every
+   * level and keeps every row; window_perms > 0 fixes the permutation window (all devices must walk the same ones) */
+  int shard_rank, shard_world, window_perms;
 } gcre_pp_input;
 
 /* out[0..4] = lst1..lst5; entries above path_length have n = -1 (R sees NULL, wrapper.cpp:223). */
 int gcre_process_paths(gcre_ctx* ctx, const gcre_pp_input* in, gcre_result out[5]);
+
+/* The same call on several GPUs of one node from ONE process -- what the .Call shim uses, so that the drop-in takes the
+ * node like the reference takes `nthreads` cores (src/join_base.cpp:163-185, src/wrapper.cpp:189).  One context and one
+ * host thread per device; every device scores 1/n of each level's joined paths (contiguous ordinals, src/join_base.cpp:230
+ * workers pull uids the same way) and keeps every row; the per-permutation null maxima are MAX-merged and the top-k
+ * tables merged with the sentinel rule on the host when the devices are done (K floats + top_k rows per level and
+ * device: the message sizes of SURVEY.md 2.2).  devices = NULL: devices 0 .. n_devices-1; n_devices <= 0: every visible
+ * device; a device may be listed twice (rehearsal on one GPU).  Results are bit-identical for any device list.
+ * err / errlen: optional buffer for the failing device's message. */
+int gcre_process_paths_devices(int method, int n_cases, int n_ctrls, int iterations, int top_k, const int* devices,
+                               int n_devices, const gcre_pp_input* in, gcre_result out[5], char* err, size_t errlen);
 
 /* uid resolution of assemble_uids (src/wrapper.cpp:106-132): row k takes (count, location) of the entry
  * keyed by trg_uids[k]; missing keys give (0, 0). */

@@ -316,3 +316,16 @@ def test_gwaspa_front_end_matches_oracle_and_finds_planted_pathway(signed):
         np.testing.assert_array_equal(g.scores.view(np.uint64), w.scores.view(np.uint64))
         np.testing.assert_array_equal(g.cases, w.cases)
         np.testing.assert_array_equal(g.ctrls, w.ctrls)
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_process_paths_on_several_devices_from_one_process(method, devices):
+    """gcre_process_paths_devices (what the .Call shim calls): one context and host thread per listed device, joined paths
+    sharded, maxima and top-k tables merged on the host -- rehearsed here with the one GPU of the box listed up to three
+    times.  Bit-identical to the oracle (and hence to the single-context call) for every device list."""
+    p = make_problem(70, 260, 33, 41, 2300, 5, method=method, top_k=11, seed=21, table=small_table(33, 41, 5))
+    want = oracle.process_paths(p, order="canonical", nthreads=4)
+    got = api.process_paths_devices(p, devices)
+    for lvl in range(1, 6):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
