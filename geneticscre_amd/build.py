@@ -41,5 +41,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HARNESS_SRC = os.path.join(PKG, "..", "tools", "harness", "gcre_harness.cpp")
+HARNESS_BIN = os.path.join(PKG, "..", "tools", "harness", "gcre_harness")
+
+
+def build_harness(force: bool = False, verbose: bool = False) -> str:
+    """The native stand-alone driver (the counterpart of the reference's test/harness.cpp): plain g++, loads
+    libgcre_hip.so at run time."""
+    src, out = os.path.abspath(HARNESS_SRC), os.path.abspath(HARNESS_BIN)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(PKG, "..", "include"), src, "-ldl", "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_harness(force=True, verbose=True))

@@ -329,3 +329,32 @@ def test_process_paths_on_several_devices_from_one_process(method, devices):
     got = api.process_paths_devices(p, devices)
     for lvl in range(1, 6):
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+
+
+def test_native_harness_reproduces_the_reference_harness_output():
+    """tools/harness/gcre_harness (the counterpart of the reference's test/harness.cpp) on SURVEY.md Appendix B's dump
+    with the flags of the four recorded runs of the unmodified reference binary: the printed level-4 scores and null
+    maxima are the reference's, ids wherever the score is not tied (App. A-9)."""
+    import json
+    import os
+    import re
+    import subprocess
+    from geneticscre_amd import build as hip_build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = hip_build.build_harness()
+    gold = json.load(open(os.path.join(root, "tests", "golden", "appendix_b_expected.json")))
+    for case in gold["cases"]:
+        out = subprocess.run([exe, "-f", os.path.join(root, "tests", "golden", "appendix_b_tiny.txt"), "-p", str(case["iterations"]),
+                              "-m", case["method"], "-l", str(case["path_length"]), "-k", str(case["top_k"]), "--lib", api.lib_path()],
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        res = re.search(r"results : (\d+) \|(.*)", out.stdout)
+        got = [(float(m.group(1)), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"(-?inf|-?[0-9.]+)\[(-?\d+):(-?\d+)\]", res.group(2))]
+        want_scores = [float(s) for s in case["scores"]]
+        assert [g[0] for g in got] == want_scores and int(res.group(1)) == len(want_scores)
+        perms = [float(v) for v in re.search(r"perms :(.*)", out.stdout).group(1).split()]
+        assert perms == [float(v) for v in case["null"]]
+        for (s, a, b), (ea, eb) in zip(got, case["ids"]):
+            if want_scores.count(s) == 1:
+                assert (a, b) == (ea, eb)
+        assert out.stdout.rstrip().endswith("done")
