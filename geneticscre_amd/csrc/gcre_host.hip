@@ -155,11 +155,11 @@ struct gcre_ctx {
 struct gcre_recipe {
   uint64_t a_id = 0, z_id = 0;     // the operands: path-set ids and the versions of their rows
   uint64_t a_ver = 0, z_ver = 0;
-  DevBuf<uint32_t> row0, rowz, linfo, lover, slot, over;
+  DevBuf<uint32_t> row0, rowz, linfo, lover, slot, over, tot;   // tot: carriers of every kept row
   uint32_t max_len = 0;            // longest list (padded) the producing join's inspector wrote
   bool valid = false;
   void release() {
-    for (auto* b : {&row0, &rowz, &linfo, &lover, &slot, &over}) b->release();
+    for (auto* b : {&row0, &rowz, &linfo, &lover, &slot, &over, &tot}) b->release();
     valid = false;
   }
 };
@@ -1126,6 +1126,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (e == hipSuccess) e = rcp->rowz.reserve(rows + 64);
           if (e == hipSuccess) e = rcp->linfo.reserve(rows + 64);
           if (e == hipSuccess) e = rcp->lover.reserve(rows + 64);
+          if (e == hipSuccess) e = rcp->tot.reserve(rows + 64);
           if (e == hipSuccess) e = rcp->slot.reserve(rows * 8 + 64);
           if (e == hipSuccess) e = rcp->over.reserve(std::max<size_t>(rcp->over.cap, rows * 2 + ((size_t)1 << 26)));
           if (e != hipSuccess) {
@@ -1267,6 +1268,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sa.ov_count = c->d_max_tot + 4;
           sa.zoff = (uint32_t)(64 * g.Wp) << 8;
           HIP_TRY(c, launch_stats_ie(sa, g.method, st));
+          // a kept row's carrier total bounds every count of it: the next level loads only the plane groups that can be non-zero
+          if (rcp) HIP_TRY(c, hipMemcpyAsync(rcp->tot.p + cb, c->d_tot.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         } else {
           HIP_TRY(c, launch_stats(sa, g.method, st));
         }
@@ -1370,7 +1373,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             ia.rec_gz = rec_z->plane_groups;
             // the recipe entries of every segment's row, next to the segment table (no load depends on row0 any more)
             HIP_TRY(c, c->d_rec_segs.reserve((size_t)std::max<int64_t>(ia.nsegs, 1) * kRecSegWords));
-            HIP_TRY(c, launch_fill_rec_segs(ia.segs, ia.nsegs, r0->row0.p, r0->rowz.p, r0->linfo.p, r0->lover.p, r0->slot.p,
+            HIP_TRY(c, launch_fill_rec_segs(ia.segs, ia.nsegs, r0->row0.p, r0->rowz.p, r0->linfo.p, r0->lover.p, r0->slot.p, r0->tot.p,
                                             c->d_rec_segs.p, st));
             ia.rec_segs = c->d_rec_segs.p;
           }
@@ -1449,11 +1452,15 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
                 ensure_quads(c, u, *seg_entry, ia.seg_begin) == GCRE_OK) {
               const int64_t nq = seg_entry->nquads - seg_entry->quad_begin;
               quad = nq > 0 && ((ia.seg_end - ia.seg_begin) * 2 >= nq * 3 || c->ie_quad == 2);   // 1.5 segments per quad on average
+              if (std::getenv("GCRE_HOST_TIMING"))
+                std::fprintf(stderr, "[host] quads: %lld segments in %lld quads (%.2f per quad), %lld joined paths, quad form %s\n",
+                             (long long)(ia.seg_end - ia.seg_begin), (long long)nq, (double)(ia.seg_end - ia.seg_begin) / (double)std::max<int64_t>(nq, 1),
+                             (long long)n, quad ? "on" : "off");
               if (quad) {
                 ia.quads = seg_entry->d_quads;
                 ia.quad_begin = seg_entry->quad_begin;
                 ia.quad_end = seg_entry->nquads;
-                ia.batch = std::max(1, c->ie_batch / 2);   // a quad is up to four segments
+                ia.batch = std::max(1, c->ie_batch * 2);   // quads per ticket: the headers of a ticket's quads are fetched one ahead
                 const int wq = std::min(c->sparse_waves_per_cu, ieq_max_waves_per_cu(planes, ia.gz, ia.rec_slot != nullptr));
                 ia.waves_per_xcd = std::max(4, (dev_cus * wq / 8 / 4) * 4);
                 while (ia.waves_per_xcd > 4 && n * ie_tile_factor < (int64_t)8 * ia.waves_per_xcd * 128)
@@ -1475,7 +1482,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             HIP_TRY(c, hipStreamSynchronize(st));
             const double waves = 8.0 * ia.waves_per_xcd;
             if (ie_quad_ran)
-              std::fprintf(stderr, "[ieq timing] paths %lld waves %.0f iterations/wave %.0f: per-wave Mcycles head %.2f sums %.2f long %.2f fetch %.2f counts(incl lookups) %.2f lookups %.2f total %.2f\n",
+              std::fprintf(stderr, "[ieq timing] paths %lld waves %.0f quads/wave %.0f: per-wave Mcycles header+loads %.2f base counters %.2f intervals %.2f filter pass %.2f exact pass %.2f exchange %.2f total %.2f\n",
                            (long long)n, waves, tmv[7] / waves, tmv[0] / waves / 1e6, tmv[1] / waves / 1e6, tmv[2] / waves / 1e6, tmv[3] / waves / 1e6,
                            tmv[4] / waves / 1e6, tmv[5] / waves / 1e6, tmv[6] / waves / 1e6);
             else

@@ -1243,7 +1243,8 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
 // next to the segment table (kRecSegWords words: paths0 row of the producing join, row it added, list info, where a
 // long list continues, the list's first 8 entries) so that the pruned kernel needs no load that depends on row0.
 __global__ __launch_bounds__(256) void k_fill_rec_segs(const SparseSeg* segs, i64 nsegs, const u32* r_row0, const u32* r_rowz,
-                                                       const u32* r_linfo, const u32* r_lover, const u32* r_slot, u32* out) {
+                                                       const u32* r_linfo, const u32* r_lover, const u32* r_slot, const u32* r_tot,
+                                                       u32* out) {
   const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   const i64 sidx = t >> 2;
   const int part = (int)(t & 3);   // four threads per segment: the four scalars, then the slot in two halves
@@ -1254,7 +1255,13 @@ __global__ __launch_bounds__(256) void k_fill_rec_segs(const SparseSeg* segs, i6
     o[0] = r_row0[row0];
     o[1] = r_rowz[row0];
   } else if (part == 1) {
-    o[2] = r_linfo[row0];
+    u32 info = r_linfo[row0];
+    u32 need = 3u;   // plane groups of the row that can be non-zero, minus one: ceil(bits(carriers) / 4) - 1
+    if (r_tot) {
+      const u32 t = r_tot[row0];
+      need = t < 16u ? 0u : (t < 256u ? 1u : (t < 4096u ? 2u : 3u));
+    }
+    o[2] = info | (need << 1);
     o[3] = r_lover[row0];
   } else {
     const u32x4 v = *(const u32x4*)(r_slot + (u64)row0 * 8u + (part - 2) * 4);
@@ -1263,12 +1270,12 @@ __global__ __launch_bounds__(256) void k_fill_rec_segs(const SparseSeg* segs, i6
 }
 
 hipError_t launch_fill_rec_segs(const SparseSeg* segs, int64_t nsegs, const uint32_t* r_row0, const uint32_t* r_rowz,
-                                const uint32_t* r_linfo, const uint32_t* r_lover, const uint32_t* r_slot, uint32_t* out,
-                                hipStream_t stream) {
+                                const uint32_t* r_linfo, const uint32_t* r_lover, const uint32_t* r_slot, const uint32_t* r_tot,
+                                uint32_t* out, hipStream_t stream) {
   if (nsegs == 0) return hipSuccess;
   const i64 blocks = (nsegs * 4 + 255) / 256;
   hipLaunchKernelGGL(k_fill_rec_segs, dim3((unsigned)blocks), dim3(256), 0, stream, segs, nsegs, r_row0, r_rowz, r_linfo, r_lover,
-                     r_slot, out);
+                     r_slot, r_tot, out);
   return hipGetLastError();
 }
 

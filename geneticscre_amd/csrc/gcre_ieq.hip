@@ -23,6 +23,15 @@ namespace gcre {
 
 constexpr int kQSegs = 4;
 
+// -DGCRE_IE_TIMING: per-section s_memtime sums (a mark only reads the clock)
+#ifdef GCRE_IE_TIMING
+#define GCRE_QT(var) const u64 var = __builtin_amdgcn_s_memtime()
+#define GCRE_QT_ADD(i, t1, t0) tm[i] += (t1) - (t0)
+#else
+#define GCRE_QT(var)
+#define GCRE_QT_ADD(i, t1, t0)
+#endif
+
 template <int L, int GZ, bool REC>
 __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3))) void k_null_ie_q(const IeArgs a) {
   constexpr int LP = (L + 3) / 4 * 4;
@@ -47,7 +56,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
   const u32 k_lad_mode = uni((u32)a.lad_mode), k_score_segs = uni(a.score_segs);
   const char* k_mt = uni_ptr(a.mt);
   const char* k_planesz = uni_ptr(a.planesz);
-  const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
 
   int cur_kt = -1;
   u32 valid = 0u;
@@ -55,6 +63,10 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
   const u32 lad_keep = (u32)kLadderLevels * k_lstride;
   bool dirty = false;
   u32 n_slow = 0u;
+#ifdef GCRE_IE_TIMING
+  u64 tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // header + loads issued, base counters, filter intervals, filter pass, exact pass, exchange, total, quads
+  const u64 tm_begin = __builtin_amdgcn_s_memtime();
+#endif
   __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)k_mt, 0, 0x7fffffff, 0x00020000);
 
   // publish the wave's maxima, read everybody's, set the threshold level to the smallest running maximum of the tile's
@@ -125,18 +137,54 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
       since = 0;
       period = 1;
     }
+    // The table entries of a quad's segments -- (row0, first, n) and, with a recipe, the twelve words k_fill_rec_segs
+    // gathered per segment -- are wave-uniform, but a scalar load of them misses all the way to HBM (the tables are tens
+    // of MB and every entry is read once): four dependent round trips per quad.  They are fetched one quad ahead into
+    // one vector register per segment (lane l = word l) and moved to scalar registers with v_readlane.
+    auto load_hdr = [&](u32 qe_, u32 (&h)[kQSegs]) {
+      const u32 cnt_ = (qe_ >> 30) + 1u, s0_ = qe_ & 0x3fffffffu;
+#pragma unroll
+      for (int g = 0; g < kQSegs; g++) {
+        h[g] = 0u;
+        if ((u32)g < cnt_) {
+          const u32* src = (const u32*)a.segs + (u64)(s0_ + (u32)g) * 3u + (u32)(lane < 3 ? lane : 0);
+          if constexpr (REC) {
+            if (lane >= 4 && lane < 16) src = a.rec_segs + (u64)(s0_ + (u32)g) * kRecSegWords + (u32)(lane - 4);
+          }
+          h[g] = *src;
+        }
+      }
+    };
+    u32 hdr_n[kQSegs] = {0u, 0u, 0u, 0u};
+    u32 qe_n = 0u;
+    bool have_next = false;
     for (u32 qi = q_lo; qi < q_hi; qi++) {
       // ---- the quad: up to four consecutive segments of the table, same added rows, same length ----
-      const u32 qe = uni(((const u32 GCRE_CONSTANT*)a.quads)[qi]);
+      GCRE_QT(t0);
+      u32 hdr[kQSegs];
+      u32 qe;
+      if (have_next) {
+        qe = qe_n;
+#pragma unroll
+        for (int g = 0; g < kQSegs; g++) hdr[g] = hdr_n[g];
+      } else {
+        qe = uni(((const u32 GCRE_CONSTANT*)a.quads)[qi]);
+        load_hdr(qe, hdr);
+      }
+      have_next = qi + 1u < q_hi;
+      if (have_next) qe_n = uni(((const u32 GCRE_CONSTANT*)a.quads)[qi + 1u]);   // its headers go out below, behind this quad's loads
       const u32 qcnt = (qe >> 30) + 1u;
       const u32 s0 = qe & 0x3fffffffu;
-      const u32 npaths = uni(segs[s0].n);
+      const u32 npaths = rdlane(hdr[0], 2);
       const u32 last = npaths - 1u;
+      GCRE_QT(te0);
       if (k_lad_mode == 0u && ++since >= period) {
         exchange();
         since = 0;
         period = period < kIeRefresh ? period * 2 : kIeRefresh;
       }
+      GCRE_QT(te1);
+      GCRE_QT_ADD(5, te1, te0);
       const u32 lad_row = (s0 < k_score_segs) ? lad_base : lad_keep;
 
       // ---- per segment: the metadata of its paths (lane t <-> path first + t) and its base counters ----
@@ -158,40 +206,54 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
       u32 totv[kQSegs];
       u32 yr[REC ? kQSegs : 1][8];
       u32 rinfo_g[kQSegs] = {0u, 0u, 0u, 0u}, rlov_g[kQSegs] = {0u, 0u, 0u, 0u}, rz_g[kQSegs] = {0u, 0u, 0u, 0u};
+      // the paths' metadata first: the ladder gather below needs the carrier totals and must not queue behind the planes
 #pragma unroll
       for (int g = 0; g < kQSegs; g++) {
+        totv[g] = 0u;
         if ((u32)g < qcnt) {
-          const u32 sidx = s0 + (u32)g;
-          const u32 row0 = uni(segs[sidx].row0), first = uni(segs[sidx].first);
+          const u32 first = rdlane(hdr[g], 1);
           firstg[g] = first;
           const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
           infov[g] = a.linfo[qv];
           totv[g] = a.tot[qv];
           if (g == 0) zunit = ((u32)kt * (u32)a.rowsz + (a.rowz[qv] & 0x7fffffffu)) * (u32)a.gz;   // the same for every segment of the quad
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < kQSegs; g++) {
+        if ((u32)g < qcnt) {
+          const u32 row0 = rdlane(hdr[g], 0);
           u32 Bp[LP];
           if constexpr (!REC) {
             load_groups(Bp, a.planes0, ((u64)kt * (u64)a.rows0 + (u64)row0) * (u64)a.g0, a.g0);
           } else {
             // the segment's recipe words sit next to the segment table (k_fill_rec_segs): paths0 row of the producing
             // join, row it added, list info, where a long list continues, the list's first 8 entries
-            const u32 GCRE_CONSTANT* rs = (const u32 GCRE_CONSTANT*)a.rec_segs + (u64)sidx * kRecSegWords;
-            const u32 ra = uni(rs[0]);
-            rz_g[g] = uni(rs[1]) & 0x7fffffffu;
-            rinfo_g[g] = uni(rs[2]);
-            rlov_g[g] = uni(rs[3]);
-            const u32x8 ro = *(const u32x8 GCRE_CONSTANT*)(rs + 4);
+            const u32 ra = rdlane(hdr[g], 4);
+            rz_g[g] = rdlane(hdr[g], 5) & 0x7fffffffu;
+            rinfo_g[g] = rdlane(hdr[g], 6);
+            rlov_g[g] = rdlane(hdr[g], 7);
+            u32 ro[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) ro[j] = rdlane(hdr[g], 8 + j);
             const u32 rtrue = (rinfo_g[g] & kLinfoLenMask) - (rinfo_g[g] >> 28);   // entries that are not padding
 #pragma unroll
             for (int j = 0; j < 8; j++) {
               yr[REC ? g : 0][j] = 0u;
-              if ((u32)j < rtrue) yr[REC ? g : 0][j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, uni(ro[j]), 0);
+              if ((u32)j < rtrue) yr[REC ? g : 0][j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, ro[j], 0);
             }
-            load_groups(Bp, a.rec_planes_a, ((u64)kt * (u64)a.rec_rows_a + (u64)ra) * (u64)a.rec_ga, a.rec_ga);
+            // the row's carrier total bounds the counts of everything it was made from: planes above it are zero and are
+            // not read (3 KB -> 2 KB of HBM per segment and tile for most rows: this load is the kernel's HBM traffic)
+            const int ga_need = (int)((rinfo_g[g] >> 1) & 3u) + 1;
+            load_groups(Bp, a.rec_planes_a, ((u64)kt * (u64)a.rec_rows_a + (u64)ra) * (u64)a.rec_ga, ga_need < a.rec_ga ? ga_need : a.rec_ga);
           }
 #pragma unroll
           for (int l = 0; l < L; l++) B[g][l] = Bp[l];
         }
       }
+      if (have_next) load_hdr(qe_n, hdr_n);
+      GCRE_QT(t1);
+      GCRE_QT_ADD(0, t1, t0);
       // (b) with a recipe: row = A + Z -/+ list.  The segments of a quad end in the same pivot gene, so the row the
       // producing join added -- that gene -- is the same for all of them: its planes are loaded once
       if constexpr (REC) {
@@ -250,6 +312,8 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
           }
         }
       }
+      GCRE_QT(t2);
+      GCRE_QT_ADD(1, t2, t1);
       // (c) the filter's interval per path, ready to use: [lo + ov, hi] packed as hi << 16 | lo; the empty interval (lo 1,
       // hi 0: "everything is outside") for delta lists and for bounds the margin pushes out of range
 #pragma unroll
@@ -265,6 +329,8 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
         }
       }
 
+      GCRE_QT(t3);
+      GCRE_QT_ADD(2, t3, t2);
       const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)a.dlist;
       auto issue = [&](u32 t2, u32 (&ZZ)[LZ]) {
         __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(k_planesz + (u64)rdlane(zunit, t2) * 1024u), 0, 0x7fffffff, 0x00020000);
@@ -323,13 +389,16 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
         }
       }
 
+      GCRE_QT(t4);
+      GCRE_QT_ADD(3, t4, t3);
       // ---- second pass: the marked paths, exactly.  The planes of the added row again, the mask rows of the list's real
       // entries, count = B + Nz - S (or B + S), the interval test, look-ups for what falls outside -- with the loads of
       // the next marked path in flight while this one is computed.
-      struct Item { u32 info, lov, tot, lh; u32x8 o; };
+      struct Item { u32 t, info, lov, tot, lh; u32x8 o; };
       auto item_meta = [&](int g, u32 t) -> Item {
         Item it;
         const u64 q = (u64)firstg[g] + t;
+        it.t = t;
         it.info = rdlane(infov[g], t);
         it.lh = rdlane(lhv[g], t);
         it.lov = ((const u32 GCRE_CONSTANT*)a.lover)[q];
@@ -337,14 +406,14 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
         it.o = slots[q];
         return it;
       };
-      auto item_issue = [&](const Item& it, u32 t, u32 (&yy)[8], u32 (&ZZ)[LZ]) {
+      auto item_issue = [&](const Item& it, u32 (&yy)[8], u32 (&ZZ)[LZ]) {
         const u32 ov = (it.info & kLinfoLenMask) - (it.info >> 28);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           yy[j] = 0u;
           if ((u32)j < ov) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, it.o[j], 0);   // padding entries are not fetched
         }
-        if (it.info & 1u) issue(t, ZZ);
+        if (it.info & 1u) issue(it.t, ZZ);
       };
       auto exact_f = [&](const Item& it, const u32 (&Bg)[L], const u32 (&y)[8], const u32 (&Z)[LZ]) {
         const u32 len = it.info & kLinfoLenMask;
@@ -407,6 +476,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
         u32 m = (blo | bhi) & valid;
         if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) return;
         n_slow++;
+        dirty = true;
         const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(it.tot);
         while (m != 0u) {
           u32 bb[4], vv[4];
@@ -423,8 +493,10 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
           for (int k = 0; k < 4; k++)
             __hip_atomic_fetch_max(nm + bb[k] * 64, vv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_max_u32
         }
-        dirty = true;
       };
+#ifdef GCRE_IEQ_NOEXACT   // diagnostics: the cost of the first pass alone (results are wrong)
+      if (B[0][0] == 0x12345678u && B[1][1] == 1u && B[2][2] == 2u && B[3][3] == 3u)
+#endif
 #pragma unroll
       for (int g = 0; g < kQSegs; g++) {
         if ((u32)g < qcnt && todo[g] != 0ull) {
@@ -432,35 +504,46 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
           u32 yA[8], yB[8], ZA[LZ], ZB[LZ];
 #pragma unroll
           for (int l = 0; l < LZ; l++) ZA[l] = ZB[l] = 0u;
-          u32 tA = (u32)__builtin_ctzll(m);
-          m &= m - 1ull;
-          Item iA = item_meta(g, tA), iB = iA;
-          item_issue(iA, tA, yA, ZA);
+          // three stages: the list entries and totals of a marked path are read (scalar loads) while the path before it
+          // has its rows and planes in flight and the one before that is computed
+          auto pop = [&]() -> u32 {
+            const u32 t = (u32)__builtin_ctzll(m);
+            m &= m - 1ull;
+            return t;
+          };
+          Item cur = item_meta(g, pop()), nxt = cur, aft = cur;
+          bool has_n = m != 0ull, has_a = false;
+          if (has_n) nxt = item_meta(g, pop());
+          item_issue(cur, yA, ZA);
           for (;;) {
-            const bool moreB = m != 0ull;
-            if (moreB) {
-              const u32 tB = (u32)__builtin_ctzll(m);
-              m &= m - 1ull;
-              iB = item_meta(g, tB);
-              item_issue(iB, tB, yB, ZB);
-            }
-            exact_f(iA, B[g], yA, ZA);
-            if (!moreB) break;
-            const bool moreA = m != 0ull;
-            if (moreA) {
-              tA = (u32)__builtin_ctzll(m);
-              m &= m - 1ull;
-              iA = item_meta(g, tA);
-              item_issue(iA, tA, yA, ZA);
-            }
-            exact_f(iB, B[g], yB, ZB);
-            if (!moreA) break;
+            if (has_n) item_issue(nxt, yB, ZB);
+            has_a = m != 0ull;
+            if (has_a) aft = item_meta(g, pop());
+            exact_f(cur, B[g], yA, ZA);
+            if (!has_n) break;
+            cur = nxt; nxt = aft; has_n = has_a;
+            if (has_n) item_issue(nxt, yA, ZA);
+            has_a = m != 0ull;
+            if (has_a) aft = item_meta(g, pop());
+            exact_f(cur, B[g], yB, ZB);
+            if (!has_n) break;
+            cur = nxt; nxt = aft; has_n = has_a;
           }
         }
       }
+      GCRE_QT(t5);
+      GCRE_QT_ADD(4, t5, t4);
+#ifdef GCRE_IE_TIMING
+      tm[7] += 1;
+#endif
     }
   }
   flush_tile();
+#ifdef GCRE_IE_TIMING
+  tm[6] = __builtin_amdgcn_s_memtime() - tm_begin;
+  if (a.timing && lane == 0)
+    for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)a.timing + i, (unsigned long long)tm[i]);
+#endif
   if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
 }
 

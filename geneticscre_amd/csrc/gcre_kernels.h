@@ -149,9 +149,11 @@ struct IeArgs {
 };
 hipError_t launch_null_ie_quad(const IeArgs& a, int planes, hipStream_t stream);   // gcre_ieq.hip
 int ieq_max_waves_per_cu(int planes, int gz, bool rec);
+// r_tot (optional): carriers of the recipe's rows; bits 1-2 of the gathered list-info word then say how many groups of 4
+// count planes of the row can be non-zero, minus one (counts never exceed the carrier total)
 hipError_t launch_fill_rec_segs(const SparseSeg* segs, int64_t nsegs, const uint32_t* r_row0, const uint32_t* r_rowz,
-                                const uint32_t* r_linfo, const uint32_t* r_lover, const uint32_t* r_slot, uint32_t* out,
-                                hipStream_t stream);
+                                const uint32_t* r_linfo, const uint32_t* r_lover, const uint32_t* r_slot, const uint32_t* r_tot,
+                                uint32_t* out, hipStream_t stream);
 hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general, hipStream_t stream);
 int ie_max_waves_per_cu(int method, int planes, int gz, bool out, bool rec);
 hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, const uint64_t* loff, const uint32_t* lidx,
