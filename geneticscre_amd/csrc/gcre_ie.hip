@@ -22,6 +22,8 @@
 // all 2048 counts of a path against (lo, hi); only when some permutation falls outside does the wave transpose its
 // counters and look the table up (finish_m1).  Skipping a lookup whose value cannot exceed the maximum leaves every
 // maximum bit-identical.
+#include <cstdlib>
+
 #include "gcre_ie_common.h"
 
 namespace gcre {
@@ -1805,8 +1807,230 @@ hipError_t launch_range_union(const uint64_t* p1, const uint64_t* pz, const int3
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The method-1 inspector, block-staged form.  Same outputs as k_stats_ie<1, .>, bit for bit, but organised around what
+// bounded that kernel: not its ~110 VALU instructions per path but its ~7.5 vector-memory instructions per path (the CU's
+// vector-memory pipe takes ~15 clocks per wave-level load or store whatever its width, tools/row_gather_rate.hip) -- seven
+// 4-byte stores per path by one lane in sixteen, one store per list entry, 8-byte row loads.  Here a wave owns 64
+// CONSECUTIVE joined paths: their row numbers are read with one coalesced load per array, their seven result words and
+// their 8-entry list slots are collected in LDS and written with one coalesced store per array per 64 paths, and the
+// rows are read 16 bytes per lane.  Sixteen lanes per path, four paths at a time, as before.
+// NL = 16-byte loads per row and lane = ceil(Wp / 32) (Wp <= 32 * NL).
+// ------------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_stats_ie2(const StatsArgs a) {
+  typedef u64 __attribute__((ext_vector_type(2))) u64x2;
+  constexpr u32 kNoRange = 0xffffffffu;
+  constexpr u32 kOverChunk = 2048;
+  __shared__ u32 slot_lds[4][64 * 8];   // the 64 paths' list slots
+  __shared__ u32 out_lds[4][8][64];     // their result words: tot, cases, ctrls, rowz, key lo, key hi, linfo, lover
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sl = lane & 15, grp = lane >> 4;
+  const i64 wave = (i64)blockIdx.x * 4 + wv;
+  const i64 nwaves = (i64)gridDim.x * 4;
+  const int Wp = a.Wp;
+  u32* slots = slot_lds[wv];
+  u32 (*outs)[64] = out_lds[wv];
+  u32 my_max_tot = 0, my_modes = 0, my_max_len = 0;
+  bool my_bad = false;
+  u32 chunk_at = 0u, chunk_left = 0u;
+  // this lane's words of a row: 2 sl, 2 sl + 1 of every 32-word block
+  u64 cmw[NL][2];
+#pragma unroll
+  for (int it = 0; it < NL; it++) {
+    const int k = it * 32 + 2 * sl;
+    cmw[it][0] = k < Wp ? a.case_mask[k] : 0;
+    cmw[it][1] = k + 1 < Wp ? a.case_mask[k + 1] : 0;
+  }
+  const i64 nblocks = (a.count + 63) / 64;
+  for (i64 blk = wave; blk < nblocks; blk += nwaves) {
+    const i64 base = blk * 64;
+    const i64 iq = base + lane < a.count ? base + lane : a.count - 1;
+    // ---- the 64 paths' row numbers, one coalesced load per array (lane t <-> path base + t) ----
+    const u32 r0v = a.row0[iq];
+    const u32 r1v = a.row1[iq];
+    const u32 zv = a.zindex ? (u32)a.zindex[r1v & 0x7fffffffu] : (r1v & 0x7fffffffu);
+    u32 rngv = kNoRange;   // the uid's row of the excess table, for the first path of a uid in this launch only
+    if (a.excess && (iq == 0 || a.row0[iq - 1] != r0v)) rngv = (u32)a.range_of[r0v];
+    // slots start as padding
+    {
+      const u32x4 pad = {a.zoff, a.zoff, a.zoff, a.zoff};
+      ((u32x4*)slots)[lane * 2] = pad;
+      ((u32x4*)slots)[lane * 2 + 1] = pad;
+    }
+    // the observed score is a gather from a 100-MB table (a miss all the way to HBM): its key is written one path late,
+    // so that the wave never sits on that load
+    double score_prev = 0.0;
+    int pl_prev = -1;
+    // the rows of the next four paths are requested while these four are worked on
+    u64x2 nx[NL], nz[NL];
+    u32 n_rz = 0u, n_rng = kNoRange;
+    auto fetch_rows = [&](int it4n) {
+      const int pln = it4n * 4 + grp;
+      const u32 r0n = (u32)__builtin_amdgcn_ds_bpermute(pln << 2, (int)r0v);
+      n_rz = (u32)__builtin_amdgcn_ds_bpermute(pln << 2, (int)zv) & 0x7fffffffu;
+      n_rng = (u32)__builtin_amdgcn_ds_bpermute(pln << 2, (int)rngv);
+      const u64* xn = a.p0 + (size_t)r0n * a.S;
+      const u64* zn = a.pz + (size_t)n_rz * a.S;
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+        const int k = it * 32 + 2 * sl;
+        nx[it] = u64x2{0, 0};
+        nz[it] = u64x2{0, 0};
+        if (k < Wp) {            // Wp is a multiple of 4: words k and k + 1 are both inside
+          nx[it] = *(const u64x2*)(xn + k);
+          nz[it] = *(const u64x2*)(zn + k);
+        }
+      }
+    };
+    fetch_rows(0);
+    for (int it4 = 0; it4 < 16; it4++) {
+      const int pl = it4 * 4 + grp;                 // the group's path inside the block
+      const bool active = base + pl < a.count;
+      if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+      const u32 rz = n_rz, rng = n_rng;
+      const u64* uu = (rng != kNoRange) ? a.excess + (size_t)rng * a.S : nullptr;
+      u64* out = (a.res && active) ? a.res + (size_t)(a.first + base + pl) * a.S : nullptr;
+      u64 xw[NL][2], zw[NL][2];
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+        xw[it][0] = nx[it].x; xw[it][1] = nx[it].y;
+        zw[it][0] = nz[it].x; zw[it][1] = nz[it].y;
+      }
+      fetch_rows(it4 < 15 ? it4 + 1 : 15);
+      u32 cc = 0u, dv = 0u;
+      u64 stray = 0;
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+        const int k = it * 32 + 2 * sl;
+        u64x2 uv = {0, 0};
+        if (k < Wp && uu) uv = *(const u64x2*)(uu + k);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const u64 xk = xw[it][e], zk = zw[it][e], uk = e ? uv.y : uv.x;
+          stray |= uk & ~xk;
+          const u64 j = xk | zk;
+          cc += (u32)__popcll(j & cmw[it][e]) | ((u32)__popcll(j) << 16);
+          dv += (u32)__popcll(zk & ~xk) | ((u32)__popcll(zk) << 16);
+        }
+        if (out && k < Wp) *(u64x2*)(out + k) = u64x2{xw[it][0] | zw[it][0], xw[it][1] | zw[it][1]};
+      }
+      if (stray) my_bad = true;
+      const u32 c = row_total(cc, lane), d = row_total(dv, lane);
+      const u32 inc = c & 0xffffu, tot = c >> 16, inm = tot - inc;
+      const u32 dl = d & 0xffffu, ov = (d >> 16) - dl;
+      const u32 mode = a.ie_rule ? ((ov <= 8u || ov < dl) ? 1u : 0u) : ((a.ie_bias >= 0 && ov + (u32)a.ie_bias < dl) ? 1u : 0u);
+      const u32 len = mode ? ov : dl;
+      const u32 len8 = max(8u, (len + 7u) & ~7u);
+      double score = 0.0;
+      if (active && sl == 0) {
+        my_modes += mode;
+        my_max_tot = max(my_max_tot, tot);
+        my_max_len = max(my_max_len, len8);
+        score = a.dvt[(size_t)sp_diag_offset(tot) + inc];   // vt[cases][ctrls], methods.h:90
+      }
+      // ---- the list: first 8 entries into the LDS slot, the rest into the overflow area (chunk reserved per wave) ----
+      const u32 need = (active && len8 > 8u) ? len8 - 8u : 0u;
+      const u32 n0 = rdlane(need, 0), n1 = rdlane(need, 16), n2 = rdlane(need, 32), n3 = rdlane(need, 48);
+      const u32 nsum = n0 + n1 + n2 + n3;
+      u32 ovb = 0u;
+      if (nsum != 0u) {
+        if (chunk_left < nsum) {
+          const u32 grab = nsum > kOverChunk ? nsum : kOverChunk;
+          u32 wbase = 0u;
+          if (lane == 0) wbase = atomicAdd(a.ov_count, grab);
+          chunk_at = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
+          chunk_left = grab;
+        }
+        ovb = chunk_at + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        chunk_at += nsum;
+        chunk_left -= nsum;
+      }
+      const bool ov_ok = active && len8 > 8u && (u64)ovb + (len8 - 8u) <= (u64)a.over_cap;
+      u32* over = a.over + ovb;
+      u32 mine = 0u;
+#pragma unroll
+      for (int it = 0; it < NL; it++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) mine += (u32)__popcll(mode ? (zw[it][e] & xw[it][e]) : (zw[it][e] & ~xw[it][e]));
+      u32 pos = row_scan_add(mine) - mine;
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          u64 w = mode ? (zw[it][e] & xw[it][e]) : (zw[it][e] & ~xw[it][e]);
+          const u32 k = (u32)(it * 32 + 2 * sl + e);
+          while (w) {
+            const u32 b = (u32)__builtin_ctzll(w);
+            w &= w - 1;
+            const u32 en = (k * 64u + b) << 8;
+            if (pos < 8u) { if (active) slots[pl * 8 + (int)pos] = en; }
+            else if (ov_ok) over[pos - 8u] = en;
+            pos++;
+          }
+        }
+      }
+      for (u32 p = max(len, 8u) + (u32)sl; p < len8; p += 16)   // padding of the overflow part
+        if (ov_ok) over[p - 8u] = a.zoff;
+      // ---- the path's result words into LDS, lane pl of every array ----
+      if (pl_prev >= 0) {
+        const u64 key = ie_score_key(score_prev);
+        outs[4][pl_prev] = (u32)key;
+        outs[5][pl_prev] = (u32)(key >> 32);
+      }
+      pl_prev = -1;
+      if (active && sl == 0) {
+        outs[0][pl] = tot;
+        outs[1][pl] = inc;
+        outs[2][pl] = inm;
+        outs[3][pl] = rz;
+        outs[6][pl] = len8 | mode | ((len8 - len) << 28);
+        outs[7][pl] = ovb;
+        score_prev = score;
+        pl_prev = pl;
+      }
+    }
+    if (pl_prev >= 0) {
+      const u64 key = ie_score_key(score_prev);
+      outs[4][pl_prev] = (u32)key;
+      outs[5][pl_prev] = (u32)(key >> 32);
+    }
+    // ---- 64 paths' results and slots, one coalesced store per array ----
+    if (base + lane < a.count) {
+      const i64 i = base + lane;
+      a.tot[i] = outs[0][lane];
+      a.cases[i] = outs[1][lane];
+      a.ctrls[i] = outs[2][lane];
+      a.rowz[i] = outs[3][lane];
+      a.key[i] = ((u64)outs[5][lane] << 32) | outs[4][lane];
+      a.linfo[i] = outs[6][lane];
+      a.lover[i] = outs[7][lane];
+      u32x4* dst = (u32x4*)(a.slot + (u64)i * 8u);
+      dst[0] = ((const u32x4*)slots)[lane * 2];
+      dst[1] = ((const u32x4*)slots)[lane * 2 + 1];
+    }
+  }
+  if (my_max_tot) atomicMax(a.max_tot, my_max_tot);
+  if (my_bad) *a.bad = 1u;
+  if (my_modes) atomicAdd(a.bad + 1, my_modes);
+  if (my_max_len > 8u) atomicMax(a.max_tot + 5, my_max_len);
+}
+
 hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {
   if (a.count == 0) return hipSuccess;
+  static const bool v1 = std::getenv("GCRE_STATS_V1") != nullptr;   // the per-path form (cross-check)
+  if (method == 1 && !v1 && a.Wp <= 128) {
+    const i64 nb = (a.count + 63) / 64;
+    const i64 blocks = (nb + 3) / 4;
+    const dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), block(256);
+    const int nl = (a.Wp + 31) / 32;
+    if (nl <= 1) hipLaunchKernelGGL((k_stats_ie2<1>), grid, block, 0, stream, a);
+    else if (nl == 2) hipLaunchKernelGGL((k_stats_ie2<2>), grid, block, 0, stream, a);
+    else if (nl == 3) hipLaunchKernelGGL((k_stats_ie2<3>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_stats_ie2<4>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
   const i64 blocks = (a.count + 15) / 16;   // 4 waves x 4 paths per block and pass
   const dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), block(256);
   const int nit = (a.Wp + 15) / 16;
