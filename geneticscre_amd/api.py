@@ -45,7 +45,7 @@ class gcre_profile(ctypes.Structure):
                 ("null_row_loads", ctypes.c_double), ("ie_launches", ctypes.c_int64),
                 ("ie_overlap_lists", ctypes.c_int64), ("ie_hinted_joins", ctypes.c_int64),
                 ("ie_plane_joins", ctypes.c_int64), ("ie_lookup_tiles", ctypes.c_int64), ("prepare_ms", ctypes.c_double), ("inspect_ms", ctypes.c_double),
-                ("ie_quad_launches", ctypes.c_int64)]
+                ("ie_quad_launches", ctypes.c_int64), ("inspect_replays", ctypes.c_int64)]
 
 
 class gcre_level(ctypes.Structure):
@@ -89,6 +89,7 @@ EXPORTS = [
     "gcre_process_paths", "gcre_resolve_count_locs", "gcre_build_levels", "gcre_levels_free", "gcre_values_table",
     "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask", "gcre_uids_set_reduced",
     "gcre_set_perm_window", "gcre_plan_perm_window", "gcre_process_paths_devices",
+    "gcre_set_inspect_cache", "gcre_drop_inspections",
 ]
 
 
@@ -158,6 +159,8 @@ def load_library():
     lib.gcre_uids_set_reduced.argtypes = [V, V, P, I64]
     lib.gcre_set_perm_window.argtypes = [V, I, I]
     lib.gcre_plan_perm_window.argtypes = [V, P, I]
+    lib.gcre_set_inspect_cache.argtypes = [V, I]
+    lib.gcre_drop_inspections.argtypes = [V, I]
     _LIB = lib
     return lib
 
@@ -358,6 +361,14 @@ class JoinExec:
     def set_perm_window(self, k0: int, k1: int) -> None:
         """Joins that follow score permutations [k0, k1) only (tile aligned); see gcre_set_perm_window."""
         self._check(self._lib.gcre_set_perm_window(self._h, int(k0), int(k1)))
+
+    def set_inspect_cache(self, on: bool) -> None:
+        """Keep every join's mask-independent (inspector) output with its join index; see gcre_set_inspect_cache."""
+        self._check(self._lib.gcre_set_inspect_cache(self._h, 1 if on else 0))
+
+    def drop_inspections(self, release_memory: bool = False) -> None:
+        """Forget the cached inspector outputs (the next join on every index recomputes them)."""
+        self._check(self._lib.gcre_drop_inspections(self._h, 1 if release_memory else 0))
 
     def plan_perm_window(self, set_rows) -> int:
         """Permutations per window so that the count planes of path sets with ``set_rows`` rows fit in device memory."""
@@ -591,6 +602,7 @@ class ResidentPlan:
         self._needed: Dict[tuple, Optional[Tuple[int, int]]] = {}
         self._first: Dict[str, np.ndarray] = {}
         self._window: Optional[int] = None
+        self._cache_on = False
         ex = self.ex = JoinExec(problem.method, problem.n_cases, problem.n_ctrls, problem.iterations, device)
         ex.top_k = problem.top_k
         ex.set_value_table(problem.value_table)
@@ -690,16 +702,30 @@ class ResidentPlan:
         total = self.uids[name].total_paths
         return (total * rank) // world, (total * (rank + 1)) // world
 
-    def run(self, rank: int = 0, world: int = 1, d_null_out: int = 0, on_level=None) -> Dict[str, JoinResult]:
+    def run(self, rank: int = 0, world: int = 1, d_null_out: int = 0, on_level=None,
+            keep_inspections: bool = False) -> Dict[str, JoinResult]:
         """One pass over all levels.  Large permutation counts run in windows of whole 2048-permutation tiles (the count
         planes of the kept sets are per tile and have to fit in device memory): all levels for window 0, then all levels
         for window 1, ...  ``on_level(name, result, shard, window)`` sees every (level, window) result -- its null
         maxima are those of the window's permutations; ``d_null_out`` (device pointer to K floats) receives them at
         the window's offset.  The returned results carry the first window's top-k (they do not depend on the window)
-        and the concatenated null maxima."""
+        and the concatenated null maxima.
+
+        A pass of several windows runs every join's inspector (expansion, observed scores, top-k, kept rows, lists) for the
+        first window only: the library's inspection cache is on for the pass, and forgotten when the next pass starts --
+        unless ``keep_inspections``: then a later pass over the same resident inputs starts every join at its null
+        kernel (steady state of a service that re-scores the same network against new permutations)."""
         K = self.problem.iterations
         if self._window is None:
             self._window = self.planned_window()
+        n_windows = len(range(0, max(K, 1), self._window))
+        if keep_inspections or n_windows > 1:
+            self.ex.set_inspect_cache(True)
+            if not keep_inspections:
+                self.ex.drop_inspections()
+        elif self._cache_on:
+            self.ex.set_inspect_cache(False)
+        self._cache_on = keep_inspections or n_windows > 1
         out: Dict[str, JoinResult] = {}
         nulls: Dict[str, list] = {}
         prof: Dict[str, float] = {}
@@ -722,6 +748,8 @@ class ResidentPlan:
                     out[name] = r
         if K > 0:
             self.ex.set_perm_window(0, K)
+        if self._cache_on and not keep_inspections:
+            self.ex.drop_inspections()     # this pass's inspections end with it (the buffers stay for the next pass)
         for name, r in out.items():
             r.null = np.concatenate(nulls[name]) if len(nulls[name]) > 1 else nulls[name][0]
         self.last_profile = prof

@@ -19,6 +19,7 @@
 #include <unordered_map>
 #include <thread>
 #include <functional>
+#include <deque>
 #include <vector>
 
 using namespace gcre;
@@ -66,6 +67,47 @@ struct Candidate {
   double score;
   int64_t path;   // absolute joined-path ordinal
   int32_t src, trg, cases, ctrls;
+};
+
+// top-k of a chunk: indices chosen by the radix select, their keys / counts / rows gathered and copied out
+struct Winners {
+  std::vector<uint32_t> sel, cases, ctrls, r0, r1;
+  std::vector<uint64_t> key;
+  uint32_t n = 0;
+};
+
+// What the inspector of one chunk of a join left behind -- expanded row numbers, statistics, score keys, lists, flags
+// and the chunk's top-k winners.  None of it depends on the permutation masks: with the inspection cache on
+// (gcre_set_inspect_cache) the buffers belong to the join index instead of the context's scratch, and the next
+// permutation window of the same join starts at the null kernel.
+struct ChunkInsp {
+  int64_t cb = -1, n = 0, s0 = 0, s1 = 0;
+  bool inspected = false;     // rows / statistics / keys (and kept rows) are those of this chunk
+  bool with_lists = false;    // ... written by the inclusion-exclusion inspector: lists, rowz, linfo
+  bool in_recipe = false;     // ... into the kept set's recipe (not into the buffers below)
+  bool flags_valid = false;   // host copy of the inspector's flag block
+  bool win_valid = false;     // top-k winners
+  uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  Winners win;
+  DevBuf<uint32_t> row0, row1, tot, cases, ctrls, dcnt, dlist, rowz, linfo, lover, dover;
+  DevBuf<uint64_t> key;
+  void release() {
+    for (auto* b : {&row0, &row1, &tot, &cases, &ctrls, &dcnt, &dlist, &rowz, &linfo, &lover, &dover}) b->release();
+    key.release();
+    inspected = with_lists = flags_valid = win_valid = false;
+  }
+};
+
+struct InspKey {
+  uint64_t p0_id = 0, p0_ver = 0, p1_id = 0, p1_ver = 0, red_id = 0, red_ver = 0, res_id = 0, obs_epoch = 0;
+  int64_t sb = 0, se = 0, keep_begin = 0, keep_end = 0, chunk_paths = 0;
+  int keep_mode = 0, top_k = 0, null_kernel = 0;
+  bool operator==(const InspKey& o) const {
+    return p0_id == o.p0_id && p0_ver == o.p0_ver && p1_id == o.p1_id && p1_ver == o.p1_ver && red_id == o.red_id &&
+           red_ver == o.red_ver && res_id == o.res_id && obs_epoch == o.obs_epoch && sb == o.sb && se == o.se &&
+           keep_begin == o.keep_begin && keep_end == o.keep_end && chunk_paths == o.chunk_paths && keep_mode == o.keep_mode &&
+           top_k == o.top_k && null_kernel == o.null_kernel;
+  }
 };
 
 inline double key_to_score(uint64_t k) {
@@ -123,6 +165,8 @@ struct gcre_ctx {
   int sparse_waves_per_cu = 32;
   int ie_prune = 1;                  // GCRE_IE_PRUNE=0 looks every count up (diagnostics)
   uint64_t mask_epoch = 0;           // bumped whenever the permutation masks change: count planes are per epoch
+  uint64_t obs_epoch = 0;            // bumped whenever the value table changes: observed scores (keys, winners) are per epoch
+  bool insp_cache = false;           // gcre_set_inspect_cache: a join's inspector output stays with its join index
   // permutation window [win_k0, win_k0 + win_K): what a join scores.  The whole range by default; gcre_set_perm_window
   // narrows it so that the count planes of the kept sets (one per 2048-permutation tile) fit in device memory
   int win_k0 = 0, win_K = 0;
@@ -146,6 +190,32 @@ struct gcre_ctx {
   gcre_profile prof{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_null, ev_stats;
   std::vector<hipEvent_t> ev_pool;
+};
+
+// The context's per-join scratch and a chunk's cached buffers trade places while the chunk is worked on: every kernel
+// argument keeps naming c->d_*; what the inspector writes ends up owned by the join index.
+struct InspSwap {
+  gcre_ctx* c;
+  ChunkInsp* e;
+  InspSwap(gcre_ctx* c_, ChunkInsp* e_) : c(c_), e(e_) { swap(); }
+  ~InspSwap() { swap(); }
+  InspSwap(const InspSwap&) = delete;
+  InspSwap& operator=(const InspSwap&) = delete;
+  void swap() {
+    if (!e) return;
+    std::swap(c->d_row0, e->row0);
+    std::swap(c->d_row1, e->row1);
+    std::swap(c->d_tot, e->tot);
+    std::swap(c->d_cases, e->cases);
+    std::swap(c->d_ctrls, e->ctrls);
+    std::swap(c->d_key, e->key);
+    std::swap(c->d_dcnt, e->dcnt);
+    std::swap(c->d_dlist, e->dlist);
+    std::swap(c->d_rowz, e->rowz);
+    std::swap(c->d_linfo, e->linfo);
+    std::swap(c->d_lover, e->lover);
+    std::swap(c->d_dover, e->dover);
+  }
 };
 
 // How a kept path set was made (method 1): row r = row row0[r] of set A | row rowz[r] of set Z, with the producing
@@ -214,6 +284,13 @@ struct gcre_uids {
     uint32_t* d_quads = nullptr;
   };
   mutable std::vector<SegCache> seg_cache;
+  // inspection cache (gcre_set_inspect_cache): the inspector output of the last join that ran on this index, per chunk,
+  // valid while the operands' rows, the kept set, the shard and the observed-score inputs are the same
+  mutable std::deque<ChunkInsp> insp;
+  mutable InspKey insp_key;
+  mutable bool insp_valid = false;       // the join completed: every chunk entry describes it
+  mutable bool insp_hinted = false;      // ... with the reduced operand standing (the hint was not broken)
+  mutable uint64_t insp_res_ver = 0;     // version of the kept set's rows as that join left them
   // optional hint (gcre_uids_set_reduced): paths0[idx] | paths1[loc] == paths0[idx] | red[red_index[loc]] for every
   // joined path; checked on the device for every join, ignored when it does not hold
   const gcre_pathset* red = nullptr;
@@ -783,6 +860,7 @@ void free_uids(gcre_uids* u) {
     if (sc.d_segs) (void)hipFree(sc.d_segs);
     if (sc.d_quads) (void)hipFree(sc.d_quads);
   }
+  for (auto& ci : u->insp) ci.release();
   delete u;
 }
 
@@ -919,8 +997,42 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   const bool keep = jp.res != nullptr && jp.res->nrows != 0;   // keep_paths = paths_res.size != 0, join_base.cpp:217
   if (jp.res && jp.res->nrows != 0 && jp.res->nrows != P)
     return fail(c, GCRE_ERR_ASSERT, "assertion: paths_res.size != total paths");
-  if (keep) jp.res->version++;
-  if (keep) {   // its rows are about to be rewritten: lists go, the plane buffer stays allocated for the new rows
+  // ---- inspection cache: has this very join (same operand rows, kept set, shard, table) run on this index before? ----
+  InspKey ikey;
+  bool replay = false;
+  if (c->insp_cache) {
+    ikey.p0_id = jp.p0->id; ikey.p0_ver = jp.p0->version;
+    ikey.p1_id = jp.p1->id; ikey.p1_ver = jp.p1->version;
+    if (u.red) {
+      auto it = c->live_sets.find(u.red_id);
+      if (it != c->live_sets.end() && it->second == u.red) { ikey.red_id = u.red_id; ikey.red_ver = u.red->version; }
+    }
+    ikey.res_id = jp.res ? jp.res->id : 0;
+    ikey.obs_epoch = c->obs_epoch;
+    ikey.sb = jp.sharded ? jp.shard_begin : 0;
+    ikey.se = jp.sharded ? jp.shard_end : -1;
+    ikey.keep_mode = (keep ? 1 : 0) | (jp.keep_ranged ? 2 : 0) | (jp.planes_ranged ? 4 : 0);
+    ikey.keep_begin = (jp.keep_ranged || jp.planes_ranged) ? jp.keep_begin : 0;
+    ikey.keep_end = (jp.keep_ranged || jp.planes_ranged) ? jp.keep_end : 0;
+    ikey.chunk_paths = c->chunk_paths;
+    ikey.top_k = c->top_k;
+    ikey.null_kernel = c->null_kernel;
+    replay = u.insp_valid && u.insp_key == ikey && (!keep || jp.res->version == u.insp_res_ver);
+    if (!replay) {
+      for (auto& ci : u.insp) {   // the buffers stay and serve the new chunks in turn
+        ci.inspected = ci.with_lists = ci.flags_valid = ci.win_valid = false;
+        ci.cb = -1;
+      }
+      u.insp_key = ikey;
+    }
+    u.insp_valid = false;   // until this call completes
+  } else if (u.insp_valid || !u.insp.empty()) {
+    for (auto& ci : u.insp) ci.release();
+    u.insp.clear();
+    u.insp_valid = false;
+  }
+  if (keep && !replay) jp.res->version++;
+  if (keep && !replay) {   // its rows are about to be rewritten: lists go, the plane buffer stays allocated for the new rows
     uint32_t* planes = jp.res->d_planes;
     const int groups = jp.res->plane_groups;
     const size_t pbytes = jp.res->planes_bytes;
@@ -997,12 +1109,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     const int64_t tile = cfg.path_tile;
     const int64_t chunk_cap = std::max<int64_t>(tile, (c->chunk_paths / tile) * tile);
     const size_t cap = (size_t)std::min<int64_t>(chunk_cap, ((P + tile - 1) / tile) * tile) + (size_t)tile;
-    HIP_TRY(c, c->d_row0.reserve(cap));
-    HIP_TRY(c, c->d_row1.reserve(cap));
-    HIP_TRY(c, c->d_tot.reserve(cap * g.method));
-    HIP_TRY(c, c->d_cases.reserve(cap));
-    HIP_TRY(c, c->d_ctrls.reserve(cap));
-    HIP_TRY(c, c->d_key.reserve(cap));
+    bool hint_broke_late = false;
 
     // uids (rows of paths0) with at least one joined path inside [first, first+count)
     auto uids_in = [&](int64_t first, int64_t count) {
@@ -1032,6 +1139,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     if (want_ie && u.red && u.d_red_index && u.n_red_index > u.max_loc) {
       auto it = c->live_sets.find(u.red_id);   // the caller may have freed the operand since
       hinted = it != c->live_sets.end() && it->second == u.red;
+      if (replay && !u.insp_hinted) hinted = false;   // the cached run found the hint broken: it ended on paths1 itself
     }
     const gcre_pathset* red = nullptr;
     bool have_pz = false, have_p0 = false, res_planes = false, res_planes_ok = false, use_rec = false;
@@ -1120,7 +1228,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           // written when they are small, or when the next join could not use the recipe (it needs stored planes of paths0)
           if (!jp.res->rec) jp.res->rec = new gcre_recipe();
           rcp = jp.res->rec;
-          rcp->valid = false;
+          if (!replay) rcp->valid = false;
           const size_t rows = (size_t)P;
           hipError_t e = rcp->row0.reserve(rows + 64);
           if (e == hipSuccess) e = rcp->rowz.reserve(rows + 64);
@@ -1146,12 +1254,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       }
     }
     c->prof.prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
-    // top-k of a chunk: indices chosen by the radix select, their keys / counts / rows gathered and copied out
-    struct Winners {
-      std::vector<uint32_t> sel, cases, ctrls, r0, r1;
-      std::vector<uint64_t> key;
-      uint32_t n = 0;
-    };
     auto queue_winners = [&](int64_t s0, uint32_t nsel, Winners& w) -> int {
       w.n = nsel;
       if (nsel == 0) return GCRE_OK;
@@ -1192,16 +1294,50 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         Winners win;
         const int64_t npt = (n + tile - 1) / tile;
         const int64_t padded = npt * tile;
+        // inspection cache: this chunk's buffers stand in for the context's scratch while the chunk is worked on
+        ChunkInsp* ci = nullptr;
+        if (c->insp_cache) {
+          for (auto& e : u.insp)
+            if (e.cb == cb && e.n == n) ci = &e;
+          if (!ci) {
+            for (auto& e : u.insp)   // an entry of an earlier join on this index: its buffers serve this chunk
+              if (e.cb < 0) { ci = &e; break; }
+            if (!ci) { u.insp.emplace_back(); ci = &u.insp.back(); }
+            ci->inspected = ci->with_lists = ci->flags_valid = ci->win_valid = false;
+            ci->cb = cb;
+            ci->n = n;
+          }
+          if (ci->s0 != s0 || ci->s1 != s1) ci->win_valid = false;
+          ci->s0 = s0;
+          ci->s1 = s1;
+        }
+        InspSwap swapped(c, ci);
+        HIP_TRY(c, c->d_row0.reserve(cap));
+        HIP_TRY(c, c->d_row1.reserve(cap));
+        HIP_TRY(c, c->d_tot.reserve(cap * g.method));
+        HIP_TRY(c, c->d_cases.reserve(cap));
+        HIP_TRY(c, c->d_ctrls.reserve(cap));
+        HIP_TRY(c, c->d_key.reserve(cap));
+        const bool use_ie_chunk = want_ie && (scored || res_planes || rcp != nullptr);
+        // replayed: the inspector's output is in place (rows, statistics, keys, kept rows, lists when this chunk wants them)
+        const bool hit = ci && replay && ci->inspected &&
+                         (!use_ie_chunk || (ci->with_lists && ci->flags_valid && ci->in_recipe == (rcp != nullptr)));
+        if (ci && !hit) ci->inspected = ci->with_lists = ci->flags_valid = ci->win_valid = false;
+        if (hit) c->prof.inspect_replays++;
         // the null kernel reads whole tiles: rows / totals beyond n must be valid (row 0, zero carriers)
-        if (padded > n) {
+        if (padded > n && !hit) {
           HIP_TRY(c, hipMemsetAsync(c->d_row0.p + n, 0, (size_t)(padded - n) * 4, st));
           HIP_TRY(c, hipMemsetAsync(c->d_row1.p + n, 0, (size_t)(padded - n) * 4, st));
           HIP_TRY(c, hipMemsetAsync(c->d_tot.p + (size_t)n * g.method, 0, (size_t)(padded - n) * 4 * g.method, st));
         }
-        hipEvent_t e0 = get_event(c), e1 = get_event(c);
-        HIP_TRY(c, hipEventRecord(e0, st));
-        HIP_TRY(c, launch_expand(u.d_path_idx, u.d_location, u.n_uids, u.d_signs, u.path_length, g.method,
-                                 cb, n, c->d_row0.p, c->d_row1.p, st));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (!hit) {
+          e0 = get_event(c);
+          e1 = get_event(c);
+          HIP_TRY(c, hipEventRecord(e0, st));
+          HIP_TRY(c, launch_expand(u.d_path_idx, u.d_location, u.n_uids, u.d_signs, u.path_length, g.method,
+                                   cb, n, c->d_row0.p, c->d_row1.p, st));
+        }
         StatsArgs sa{};
         sa.p0 = jp.p0->d_rows;
         sa.p1 = jp.p1->d_rows;
@@ -1218,7 +1354,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         sa.count = n;
         sa.S = g.S;
         sa.Wp = g.Wp;
-        const bool use_ie = want_ie && (scored || res_planes || rcp != nullptr);
+        const bool use_ie = use_ie_chunk;
         const bool use_sparse = scored && sparse_ok && !want_ie;
         if (partial && !use_ie && g.K > 0) {   // the join left the inclusion-exclusion form on an earlier chunk
           split = true;
@@ -1241,7 +1377,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, c->d_linfo.reserve(nl));
           HIP_TRY(c, c->d_lover.reserve(nl));
           HIP_TRY(c, c->d_dlist.reserve(nl * 8 + 16));
-          HIP_TRY(c, c->d_dover.reserve(std::max<size_t>(c->d_dover.cap, nl * 2 + ((size_t)1 << 26))));   // + the waves' chunk slack
+          // + the waves' chunk slack: every wave of the inspector may leave most of a 2048-entry reservation unused
+          const size_t over_slack = (std::min<size_t>(16384, ((size_t)n + 15) / 16 * 4) + 2) * 2048;
+          HIP_TRY(c, c->d_dover.reserve(std::max<size_t>(c->d_dover.cap, nl * 2 + over_slack)));
           sa.pz = red->d_rows;
           sa.zindex = hinted ? u.d_red_index : nullptr;
           sa.excess = hinted ? c->d_excess.p : nullptr;
@@ -1256,7 +1394,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             sa.slot = rcp->slot.p + (size_t)cb * 8;
             sa.over = rcp->over.p;
             sa.over_cap = (uint32_t)std::min<size_t>(rcp->over.cap - 16, 0xfffffff0u);
-            HIP_TRY(c, hipMemcpyAsync(rcp->row0.p + cb, c->d_row0.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+            if (!hit) HIP_TRY(c, hipMemcpyAsync(rcp->row0.p + cb, c->d_row0.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
           } else {
             sa.rowz = c->d_rowz.p;
             sa.linfo = c->d_linfo.p;
@@ -1267,17 +1405,28 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           }
           sa.ov_count = c->d_max_tot + 4;
           sa.zoff = (uint32_t)(64 * g.Wp) << 8;
-          HIP_TRY(c, launch_stats_ie(sa, g.method, st));
+          if (!hit) HIP_TRY(c, launch_stats_ie(sa, g.method, st));
           // a kept row's carrier total bounds every count of it: the next level loads only the plane groups that can be non-zero
-          if (rcp) HIP_TRY(c, hipMemcpyAsync(rcp->tot.p + cb, c->d_tot.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-        } else {
+          if (rcp && !hit) HIP_TRY(c, hipMemcpyAsync(rcp->tot.p + cb, c->d_tot.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        } else if (!hit) {
           HIP_TRY(c, launch_stats(sa, g.method, st));
         }
-        HIP_TRY(c, hipEventRecord(e1, st));
-        c->ev_stats.emplace_back(e0, e1);
+        if (!hit) {
+          HIP_TRY(c, hipEventRecord(e1, st));
+          c->ev_stats.emplace_back(e0, e1);
+          if (ci) {
+            ci->inspected = true;
+            ci->with_lists = use_ie;
+            ci->in_recipe = use_ie && rcp != nullptr;
+          }
+        }
+        if (hit && ci->win_valid && scored) {   // the chunk's top-k does not depend on the masks either
+          win = ci->win;
+          sel_done = true;
+        }
         // the top-k selection only needs the keys the inspector just wrote: its digit passes run now, their state
         // comes back with the inspector's flags, its winners are collected before the null kernel starts
-        if (use_ie && g.K > 0 && scored) {
+        if (use_ie && g.K > 0 && scored && !sel_done) {
           if (int rc = select_begin(c, s0, s1 - s0, c->top_k, &sel_state)) return rc;
           sel_begun = true;
         }
@@ -1289,8 +1438,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           const uint32_t zoff = (uint32_t)(64 * g.Wp) << 8;
           const int64_t nl = n * g.method;
           uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // max carriers, hint broken, overlap lists, -, long-list entries
-          HIP_TRY(c, hipMemcpyAsync(flags, c->d_max_tot, 32, hipMemcpyDeviceToHost, st));
-          HIP_TRY(c, hipStreamSynchronize(st));
+          if (hit) {
+            std::memcpy(flags, ci->flags, sizeof flags);   // as the inspector left them (no round trip)
+          } else {
+            HIP_TRY(c, hipMemcpyAsync(flags, c->d_max_tot, 32, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+          }
           if ((size_t)flags[4] + 16 > (rcp ? rcp->over.cap : c->d_dover.cap)) {
             // more long lists than the area holds: size it from what the pass asked for, run the chunk again (a recipe
             // keeps what the earlier chunks wrote; the failed attempt's reservation is simply left unused)
@@ -1298,6 +1451,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             if (rcp) HIP_TRY(c, rcp->over.grow_keep(want, rcp->over.cap, st));
             else HIP_TRY(c, c->d_dover.reserve(want));
             redo = true;
+            if (ci) ci->inspected = false;
             break;
           }
           const uint64_t n_list = (uint64_t)nl * 8 + flags[4];
@@ -1317,8 +1471,14 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
               res_planes_ok = false;
             }
             if (cb > sg.b || &sg != &segs.front()) recipe_broken = true;   // earlier chunks added rows of another set
+            if (cb > sg.b || &sg != &segs.front()) hint_broke_late = true;
             redo = true;
+            if (ci) ci->inspected = false;
             break;
+          }
+          if (ci && !hit) {
+            std::memcpy(ci->flags, flags, sizeof flags);
+            ci->flags_valid = true;
           }
           const int64_t nseg_est = std::max<int64_t>(uids_in(cb, n), 1);
           if (c->null_kernel == 0 && scored) {
@@ -1529,6 +1689,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hipMemcpyAsync(&max_tot, c->d_max_tot, 4, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipMemcpyAsync(&n_delta, c->d_doff.p + nl, 8, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipStreamSynchronize(st));
+          if (hit) max_tot = ci->flags[0];   // the flag block was cleared for this window; the inspector's value was kept
+          else if (ci) { ci->flags[0] = max_tot; ci->flags_valid = true; }
           if (c->null_kernel == 0) {
             // auto: price both forms for this chunk (DESIGN.md "Kernel choice").  Sparse: one mask-row load per list
             // entry per 2048-permutation tile at ~15 CU-cycles each; dense: 2 VALU ops per dword per permutation at
@@ -1637,6 +1799,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             cands.push_back(Candidate{key_to_score(win.key[i]), cb + s0 + (int64_t)win.sel[i], (int32_t)win.r0[i], (int32_t)win.r1[i],
                                       (int32_t)win.cases[i], (int32_t)win.ctrls[i]});
         }
+        if (ci && !ci->win_valid) {   // (its copies have arrived: the stream was waited for above)
+          ci->win = win;
+          ci->win_valid = true;
+        }
         select_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count();
         c->prof.paths += s1 - s0;
       }
@@ -1657,6 +1823,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     keep_planes_lo = pl_b;
     keep_planes_hi = pl_e;
     keep_max_tot = join_max_tot;
+    if (c->insp_cache) {
+      u.insp_hinted = hinted;
+      u.insp_res_ver = keep ? jp.res->version : 0;
+      u.insp_valid = !hint_broke_late;
+    }
     if (ie_ran && hinted) c->prof.ie_hinted_joins++;
     if (ie_ran && have_p0) c->prof.ie_plane_joins++;
   }
@@ -1883,6 +2054,34 @@ int gcre_set_value_table(gcre_ctx* c, const double* table, int nrow, int ncol, i
   (void)hipFree(d_raw);
   if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("set_value_table: ") + hipGetErrorString(e));
   c->have_table = true;
+  c->obs_epoch++;
+  return GCRE_OK;
+}
+
+// GCRE_INSPECT_CACHE=0: every join inspects, whatever the caller asked for (cross-check)
+static bool inspect_cache_allowed() {
+  static const bool off = std::getenv("GCRE_INSPECT_CACHE") && std::atoi(std::getenv("GCRE_INSPECT_CACHE")) == 0;
+  return !off;
+}
+
+int gcre_set_inspect_cache(gcre_ctx* c, int on) {
+  if (!c) return GCRE_ERR_ARG;
+  c->insp_cache = on != 0 && inspect_cache_allowed();
+  if (!c->insp_cache) return gcre_drop_inspections(c, 1);
+  return GCRE_OK;
+}
+
+int gcre_drop_inspections(gcre_ctx* c, int release_memory) {
+  if (!c) return GCRE_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (release_memory && c->stream) (void)hipStreamSynchronize(c->stream);
+  for (gcre_uids* u : c->live_uids) {
+    u->insp_valid = false;
+    if (release_memory) {
+      for (auto& ci : u->insp) ci.release();
+      u->insp.clear();
+    }
+  }
   return GCRE_OK;
 }
 
@@ -2295,7 +2494,9 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
   gcre_pathset *parsed1 = nullptr, *parsed2 = nullptr, *paths1 = nullptr, *paths2 = nullptr, *paths3 = nullptr;
   std::vector<gcre_pathset*> temps;
   gcre_uids** uids_to_free = nullptr;
+  bool multi_window = false, cache_before = c->insp_cache;
   auto cleanup = [&]() {
+    if (multi_window) c->insp_cache = cache_before;
     if (uids_to_free)
       for (int i = 0; i < 6; i++) { free_uids(uids_to_free[i]); uids_to_free[i] = nullptr; }
     for (auto* p : temps) gcre_pathset_free(p);
@@ -2379,6 +2580,11 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     }
   }
   std::vector<float> null_all[5];
+  // several windows: the joins of the 2nd..nth window start at their null kernels (inspection cache; the operands below
+  // are made once, so that every window joins the same sets)
+  multi_window = Kall > win;
+  if (multi_window) c->insp_cache = inspect_cache_allowed();
+  gcre_pathset *zero1 = nullptr, *input1 = nullptr, *zero2 = nullptr, *input2 = nullptr, *input_l2 = nullptr, *input_l3 = nullptr;
   for (int k0 = 0; k0 < std::max(Kall, 1); k0 += win) {
     const bool first_window = k0 == 0;
     if (Kall > 0) PP_TRY(gcre_set_perm_window(c, k0, std::min(Kall, k0 + win)));
@@ -2400,23 +2606,19 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 1);
       if (!paths1) paths1 = new_pathset(c, total_paths(in->level[0]), true);
       PP_REQUIRE(paths1);
-      gcre_pathset* zero1 = gcre_pathset_zeros(c, in->n_data_inds[0]);
+      if (!zero1) temps.push_back(zero1 = gcre_pathset_zeros(c, in->n_data_inds[0]));
       PP_REQUIRE(zero1);
-      temps.push_back(zero1);
-      gcre_pathset* input1 = gcre_pathset_select(c, parsed1, in->data_inds[0], in->n_data_inds[0]);
+      if (!input1) temps.push_back(input1 = gcre_pathset_select(c, parsed1, in->data_inds[0], in->n_data_inds[0]));
       PP_REQUIRE(input1);
-      temps.push_back(input1);
       PP_TRY(join(1, 0, zero1, input1, paths1, nullptr, parsed1, in->data_inds[0], in->n_data_inds[0]));   // result discarded, wrapper.cpp:233
 
       if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 1);
-      gcre_pathset* zero2 = gcre_pathset_zeros(c, in->n_data_inds[1]);
+      if (!zero2) temps.push_back(zero2 = gcre_pathset_zeros(c, in->n_data_inds[1]));
       PP_REQUIRE(zero2);
-      temps.push_back(zero2);
       if (!parsed2) parsed2 = gcre_pathset_from_dense(c, in->data2, in->data2_rows, ncol, in->data_col_major);
       PP_REQUIRE(parsed2);
-      gcre_pathset* input2 = gcre_pathset_select(c, parsed2, in->data_inds[1], in->n_data_inds[1]);
+      if (!input2) temps.push_back(input2 = gcre_pathset_select(c, parsed2, in->data_inds[1], in->n_data_inds[1]));
       PP_REQUIRE(input2);
-      temps.push_back(input2);
       PP_TRY(join(1, 1, zero2, input2, nullptr, &out_w[0], parsed2, in->data_inds[1], in->n_data_inds[1]));
     }
     if (L >= 2) {   // wrapper.cpp:246-253
@@ -2427,18 +2629,18 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       // whose operand is this set -- which then must not be recipe-only itself (it would be rebuilt from bit lists)
       if (L >= 4 && c->g.method == 1 && plane_bytes(c, total_paths(in->level[3]), 2) > c->planes_out_max) paths2->planes_wanted = true;
       // the reference reads data_idx2 from r_data_inds3 (wrapper.cpp:207); R passes identical vectors
-      gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
+      if (!input_l2) temps.push_back(input_l2 = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]));
+      gcre_pathset* const input = input_l2;
       PP_REQUIRE(input);
-      temps.push_back(input);
       PP_TRY(join(2, 2, paths1, input, paths2, &out_w[1], parsed1, in->data_inds[3], in->n_data_inds[3]));
     }
     if (L >= 3) {   // wrapper.cpp:255-262
       if (!c->quiet && first_window) std::printf("Processing Path Length: %d\n", 3);
       if (!paths3) paths3 = new_pathset(c, total_paths(in->level[3]), true);
       PP_REQUIRE(paths3);
-      gcre_pathset* input = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]);
+      if (!input_l3) temps.push_back(input_l3 = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]));
+      gcre_pathset* const input = input_l3;
       PP_REQUIRE(input);
-      temps.push_back(input);
       PP_TRY(join(3, 3, paths2, input, paths3, &out_w[2], parsed1, in->data_inds[3], in->n_data_inds[3]));
     }
     if (L >= 4) {   // wrapper.cpp:264-269
@@ -2469,9 +2671,13 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       PP_TRY(join(5, 5, paths3, paths3, nullptr, &out_w[4], paths2, second.data(), (int64_t)second.size()));
     }
     fold();
-    for (auto* p : temps) gcre_pathset_free(p);   // this window's operand copies
-    temps.clear();
     if (Kall == 0) break;
+  }
+  for (auto* p : temps) gcre_pathset_free(p);   // the operand copies (the same rows served every window)
+  temps.clear();
+  if (multi_window) {
+    c->insp_cache = cache_before;
+    if (!cache_before) (void)gcre_drop_inspections(c, 1);
   }
   if (Kall > 0) PP_TRY(gcre_set_perm_window(c, 0, Kall));
   for (int i = 0; i < 5; i++) {

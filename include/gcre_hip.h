@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GCRE_ABI_VERSION 3
+#define GCRE_ABI_VERSION 4
 
 typedef enum {
   GCRE_OK = 0,
@@ -85,6 +85,7 @@ typedef struct {
   double prepare_ms;          /* host wall time: bit lists / count planes of the operands (once per set and mask epoch) */
   double inspect_ms;          /* host wall time: list offsets (scan), list fill and the syncs around them */
   int64_t ie_quad_launches;   /* of ie_launches: pruned method-1 launches that ran the four-paths-per-wave form (gcre_ieq.hip) */
+  int64_t inspect_replays;    /* chunks that started at the null kernel: their inspector output was still in place (gcre_set_inspect_cache) */
 } gcre_profile;
 
 /* ---- context: JoinExec::JoinExec, src/join_base.cpp:37-59.  method 1 = unsigned, 2 = signed. ---- */
@@ -263,6 +264,16 @@ int gcre_set_perm_window(gcre_ctx* ctx, int k0, int k1);
  * and tile (method 1: sets above the recipe limit, GCRE_PLANES_OUT_MAX_MB, store none) and should leave half of the free
  * device memory alone. */
 int gcre_plan_perm_window(gcre_ctx* ctx, const int64_t* set_rows, int n_sets);
+/* Inspection cache.  What a join computes before its permutation (null) kernel -- expanded row numbers, carrier
+ * totals, observed scores and their top-k, the kept rows, the inclusion-exclusion lists (JoinExec::join's real-label half,
+ * src/join_base.cpp:236-262 + methods.h:90-99) -- does not depend on the permutation masks.  With the cache on, that
+ * output stays with the join index (gcre_uids) it was computed for, and a later join on the same index with the same
+ * operand rows, kept set, shard, top_k and value table starts at the null kernel: the 2nd..nth permutation window of a
+ * large run, or the next pass over resident inputs.  Results are identical either way.  gcre_process_paths turns it on
+ * by itself for a call that needs more than one window.  Off by default (the buffers cost ~80 B per joined path).
+ * gcre_drop_inspections forgets what is cached (release_memory = 0 keeps the buffers for the next run). */
+int gcre_set_inspect_cache(gcre_ctx* ctx, int on);
+int gcre_drop_inspections(gcre_ctx* ctx, int release_memory);
 /* read permutation mask r back as width_ul words (bit c = patient c is a case under permutation r) */
 int gcre_get_perm_mask(gcre_ctx* ctx, int r, uint64_t* out);
 

@@ -1,0 +1,153 @@
+"""The inspection cache (gcre_set_inspect_cache): what a join computes before its permutation kernel -- the real-label half
+of JoinExec::join, src/join_base.cpp:236-262 + methods.h:90-99 -- is computed for the first permutation window only;
+later windows (and, when asked, later passes) start at the null kernel.  Results must be those of the oracle whether a
+join was replayed or not, in every kernel form, sharded or not (pytest -m gpu)."""
+import numpy as np
+import pytest
+
+import oracle
+from geneticscre_amd import api, dist
+from geneticscre_amd.synth import make_problem
+from helpers import assert_same_result
+
+pytestmark = pytest.mark.gpu
+
+LEVELS = (("1b", "lst1"), ("2", "lst2"), ("3", "lst3"), ("4", "lst4"), ("5", "lst5"))
+
+
+def problem(method, seed, K=5000, L=5):
+    return make_problem(40, 110, 310, 335, K, L, method=method, top_k=15, seed=seed, threshold=0.05)
+
+
+def check(got, want, L):
+    for name, lst in LEVELS[:L]:
+        assert_same_result(got[name], want[lst])
+
+
+@pytest.mark.parametrize("kernel", ["auto", "ie", "sparse", "dense"])
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_later_windows_start_at_the_null_kernel(method, kernel, monkeypatch):
+    """Three one-tile windows over 5000 permutations: 6 joins, each inspected once; windows 2 and 3 replay.  A second
+    pass forgets the inspections by default (it does all the work again) and keeps them when asked to."""
+    if kernel != "auto":
+        monkeypatch.setenv("GCRE_NULL_KERNEL", kernel)
+    monkeypatch.setenv("GCRE_WINDOW_TILES", "1")
+    p = problem(method, 21)
+    want = oracle.process_paths(p, order="canonical")
+    plan = api.ResidentPlan(p)
+    try:
+        joins = len(plan.names)
+        plan.set_window(2048)
+        got = plan.run()
+        check(got, want, 5)
+        assert plan.last_profile["inspect_replays"] == 2 * joins, plan.last_profile
+        first_stats = plan.last_profile["stats_kernel_ms"]
+        assert first_stats > 0
+        # default: a new pass inspects again (a bench step never reuses the previous step's work)
+        got = plan.run()
+        check(got, want, 5)
+        assert plan.last_profile["inspect_replays"] == 2 * joins
+        # steady state over resident inputs: nothing but null kernels
+        got = plan.run(keep_inspections=True)
+        check(got, want, 5)
+        assert plan.last_profile["inspect_replays"] == 2 * joins      # this pass filled the cache it keeps
+        got = plan.run(keep_inspections=True)
+        check(got, want, 5)
+        assert plan.last_profile["inspect_replays"] == 3 * joins, plan.last_profile
+        assert plan.last_profile["stats_kernel_ms"] == 0
+        # and a pass without the flag starts from scratch again
+        got = plan.run()
+        check(got, want, 5)
+        assert plan.last_profile["inspect_replays"] == 2 * joins
+    finally:
+        plan.close()
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_single_window_pass_can_be_kept_too(method, monkeypatch):
+    """One window: the cache is off unless asked for; with keep_inspections the second pass replays every join."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    p = problem(method, 22, K=2300, L=4)
+    want = oracle.process_paths(p, order="canonical")
+    plan = api.ResidentPlan(p)
+    try:
+        got = plan.run()
+        check(got, want, 4)
+        assert plan.last_profile["inspect_replays"] == 0
+        got = plan.run(keep_inspections=True)
+        check(got, want, 4)
+        assert plan.last_profile["inspect_replays"] == 0
+        got = plan.run(keep_inspections=True)
+        check(got, want, 4)
+        assert plan.last_profile["inspect_replays"] == len(plan.names)
+        assert plan.last_profile["stats_kernel_ms"] == 0
+        got = plan.run()       # cache off again: buffers released, everything recomputed
+        check(got, want, 4)
+        assert plan.last_profile["inspect_replays"] == 0
+    finally:
+        plan.close()
+
+
+def test_a_new_value_table_or_top_k_invalidates_the_cache(monkeypatch):
+    """Observed scores and the top-k depend on the table and on k: a kept inspection is not reused across them."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    p = problem("method1", 23, K=2100, L=3)
+    plan = api.ResidentPlan(p)
+    try:
+        plan.run(keep_inspections=True)
+        plan.run(keep_inspections=True)
+        assert plan.last_profile["inspect_replays"] == len(plan.names)
+        table = np.array(p.value_table, dtype=np.float64, copy=True)
+        table[table > 0] *= 0.5
+        plan.ex.set_value_table(table)
+        p2 = problem("method1", 23, K=2100, L=3)
+        p2.value_table = table
+        want = oracle.process_paths(p2, order="canonical")
+        got = plan.run(keep_inspections=True)
+        assert plan.last_profile["inspect_replays"] == 0
+        check(got, want, 3)
+        plan.ex.top_k = 7
+        p2.top_k = 7
+        want = oracle.process_paths(p2, order="canonical")
+        got = plan.run(keep_inspections=True)
+        assert plan.last_profile["inspect_replays"] == 0
+        check(got, want, 3)
+    finally:
+        plan.close()
+
+
+@pytest.mark.parametrize("chunk", ["256", "0"])
+def test_windows_of_sharded_chunked_joins_replay(chunk, monkeypatch):
+    """Two ranks, joins cut into several chunks (GCRE_CHUNK_PATHS) and two-tile windows: every chunk of every join is
+    replayed in the second window, merged results are the oracle's."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_WINDOW_TILES", "2")
+    if chunk != "0":
+        monkeypatch.setenv("GCRE_CHUNK_PATHS", chunk)
+    p = problem("method1", 24, K=5000, L=4)
+    want = oracle.process_paths(p, order="canonical")
+    parts = []
+    for rank in range(2):
+        plan = api.ResidentPlan(p)
+        parts.append(plan.run(rank=rank, world=2))
+        assert plan.last_profile["inspect_replays"] >= len(plan.names)
+        plan.close()
+    for name, lst in LEVELS[:4]:
+        null = np.maximum(parts[0][name].null, parts[1][name].null)
+        rows = [np.stack([r[name].scores, r[name].src, r[name].trg, r[name].cases, r[name].ctrls], axis=1) for r in parts]
+        best = dist.merge_topk(np.vstack(rows), p.top_k)
+        w = want[lst]
+        np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_process_paths_windows_inspect_once(method, monkeypatch):
+    """The one-shot call with forced one-tile windows: oracle results, operands made once."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_WINDOW_TILES", "1")
+    p = problem(method, 25, K=4500, L=5)
+    want = oracle.process_paths(p, order="canonical")
+    got = api.process_paths(p)
+    for lvl in range(1, 6):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])

@@ -83,7 +83,7 @@ def test_library_exports_every_declared_symbol():
     lib = api.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gcre_abi_version() == 3
+    assert lib.gcre_abi_version() == 4
     out = subprocess.run(["nm", "-D", "--defined-only", api.lib_path()], capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "gcre_" in l}
     assert declared <= exported
