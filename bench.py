@@ -7,9 +7,12 @@ One "step" = one pass of the hot path (the ProcessPaths join sequence, reference
 levels 1a, 1b, 2 .. path_length) over one synthetic problem whose inputs are already resident in HBM.
 For N > 1 it is launched by torch.distributed.run, one rank per GPU: every level's joined paths are sharded
 into N contiguous slices, each rank scores its slice, and the per-permutation null maxima (MAX all-reduce) and
-the top-k tables (all-gather + merge) are exchanged over RCCL.  Default "strong" scaling: every N scores the SAME
-workload (BASELINE configs[2]) with identical results; `--scaling weak` runs the config's permutation count PER GPU
-instead (K x N in total: more GPUs buy a finer p-value floor in the same time).
+the top-k tables (all-gather + merge) are exchanged over RCCL; inside a large join the ranks also share their running
+maxima (the pruning thresholds) a few times.  Workload: BASELINE configs[2] on one GPU; on several GPUs configs[3], the
+geometry BASELINE names for the 8-GPU run (same network, 10,000 patients, 100,000 permutations) -- `--config` overrides
+either.  "strong" scaling: the workload does not depend on N (results identical for every N; the line also carries the
+same workload timed on ONE of the GPUs, `one_gpu_same_workload`); `--scaling weak` runs the config's permutation count
+PER GPU instead (K x N in total).
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -276,7 +279,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="roofline", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: roofline (BASELINE configs[2]) on one GPU, sharded (configs[3], the geometry BASELINE names "
+                         "for 8 GPUs: 10x the permutations) on several")
     ap.add_argument("--edges", type=int, default=0, help="override the synthetic network's edge count")
     ap.add_argument("--perms", type=int, default=0)
     ap.add_argument("--carrier-rate", type=float, default=0.0,
@@ -289,6 +294,9 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the cold one-shot gcre_process_paths measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the extra passes with kept inspections")
+    ap.add_argument("--no-one-gpu-reference", action="store_true",
+                    help="N > 1: skip the two passes of the whole workload on rank 0's GPU alone")
+    ap.add_argument("--no-exchange", action="store_true", help="N > 1: ranks do not share their running maxima during a join")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + several ranks on one GPU is a rehearsal of the N > 1 path, not a measurement")
     args = ap.parse_args()
@@ -312,6 +320,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if args.config is None:
+        args.config = "roofline" if world == 1 else "sharded"
     cfg = dict(CONFIGS[args.config])
     if args.method:
         cfg["method"] = args.method
@@ -352,8 +362,20 @@ def main():
         return api.JoinResult(best[:, 0].copy(), best[:, 1].astype(np.int32), best[:, 2].astype(np.int32),
                               best[:, 3].astype(np.int32), best[:, 4].astype(np.int32), null)
 
+    def exchange(name, k0, k1):
+        # mid-join: every rank learns the others' running maxima and prunes against them (gcre_join_opts.exchange)
+        if args.backend == "gloo":
+            h = d_null[k0:k1].cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            d_null[k0:k1].copy_(h)
+        else:
+            dist.all_reduce(d_null[k0:k1], op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+
+    share = exchange if (world > 1 and not args.no_exchange) else None
+
     def step():
-        out = plan.run(rank, world, d_null_out=d_null.data_ptr(), on_level=on_level)
+        out = plan.run(rank, world, d_null_out=d_null.data_ptr(), on_level=on_level, exchange=share)
         for k, v in plan.last_profile.items():
             prof_acc[k] = prof_acc.get(k, 0) + v
         return out
@@ -385,7 +407,7 @@ def main():
     steady = None
     if not args.no_steady_state:
         def kept_step():
-            return plan.run(rank, world, d_null_out=d_null.data_ptr(), on_level=on_level, keep_inspections=True)
+            return plan.run(rank, world, d_null_out=d_null.data_ptr(), on_level=on_level, keep_inspections=True, exchange=share)
         kept_step()                                # fills the cache
         if world > 1:
             dist.barrier()
@@ -493,6 +515,23 @@ def main():
     }
     if steady is not None:
         line["steady_state"] = steady
+    if world > 1 and not args.no_one_gpu_reference:
+        # the same workload on ONE of these GPUs (rank 0 alone, the others wait): what the N-GPU value is a speed-up of
+        ref = None
+        if rank == 0:
+            plan.run(0, 1, d_null_out=d_null.data_ptr())
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            for _ in range(2):
+                plan.run(0, 1, d_null_out=d_null.data_ptr())
+            torch.cuda.synchronize()
+            one_s = (time.perf_counter() - tr) / 2
+            ref = {"ms_per_step": one_s * 1e3, "value": total_scores / one_s, "unit": "scores/s",
+                   "speedup_of_this_run": (elapsed / args.steps and one_s / (elapsed / args.steps)),
+                   "note": "same workload, same inputs, rank 0's GPU alone (2 passes after the timed region)"}
+        dist.barrier()
+        if ref is not None:
+            line["one_gpu_same_workload"] = ref
     if rank == 0 and world == 1 and not args.no_end_to_end and masks is not None:
         try:
             line["end_to_end"] = end_to_end(prob, masks, local_rank, total_scores)

@@ -35,7 +35,11 @@ class gcre_result(ctypes.Structure):
 class gcre_join_opts(ctypes.Structure):
     _fields_ = [("sharded", ctypes.c_int32), ("keep_ranged", ctypes.c_int32), ("shard_begin", ctypes.c_int64),
                 ("shard_end", ctypes.c_int64), ("d_null_out", ctypes.c_void_p), ("keep_begin", ctypes.c_int64),
-                ("keep_end", ctypes.c_int64)]
+                ("keep_end", ctypes.c_int64), ("exchanges", ctypes.c_int32), ("exchange", ctypes.c_void_p),
+                ("exchange_user", ctypes.c_void_p)]
+
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32)
 
 
 class gcre_profile(ctypes.Structure):
@@ -397,13 +401,30 @@ class JoinExec:
 
     def join(self, uids, paths0: PathSet, paths1: PathSet, paths_res: Optional[PathSet] = None,
              shard: Optional[Tuple[int, int]] = None, d_null_out: int = 0,
-             keep: Optional[Tuple[int, int]] = None, keep_mode: int = 1) -> JoinResult:
+             keep: Optional[Tuple[int, int]] = None, keep_mode: int = 1, exchange=None, exchanges: int = 0) -> JoinResult:
         """JoinExec::join (src/join_base.cpp:189-264).  ``paths_res`` receives the joined rows when given.
         ``uids`` is a UidRelSet (uploaded for this call) or a DeviceUids (already resident).  ``shard`` restricts
         scoring to a range of joined paths; ``keep`` restricts the rows written to ``paths_res`` to a range (plus
         the scored shard) -- the rows this device's shards of the later joins will read -- or, with ``keep_mode`` 2,
-        only the rows that get count planes (all rows are still written)."""
-        opts = gcre_join_opts(0, 0, 0, 0, None, 0, 0)
+        only the rows that get count planes (all rows are still written).  ``exchange(k0, k1)`` is called ``exchanges``
+        times during the join (gcre_join_opts.exchange): it MAX-all-reduces d_null_out[k0:k1] across the ranks in place."""
+        opts = gcre_join_opts(0, 0, 0, 0, None, 0, 0, 0, None, None)
+        cb = None
+        if exchange is not None and exchanges > 0:
+            if not d_null_out:
+                raise GcreError("exchange needs d_null_out")
+
+            def _cb(_user, _d_null, k0, k1):
+                try:
+                    exchange(int(k0), int(k1))
+                    return 0
+                except Exception:      # an exception must not unwind through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = EXCHANGE_FN(_cb)      # kept alive until the join returns
+            opts.exchanges = int(exchanges)
+            opts.exchange = ctypes.cast(cb, ctypes.c_void_p)
         if shard is not None:
             opts.sharded, opts.shard_begin, opts.shard_end = 1, int(shard[0]), int(shard[1])
         if keep is not None:
@@ -702,8 +723,23 @@ class ResidentPlan:
         total = self.uids[name].total_paths
         return (total * rank) // world, (total * (rank + 1)) // world
 
+    def exchange_count(self, name: str, world: int) -> int:
+        """How often a rank shares its running maxima with the others during the join of level ``name`` (the same on
+        every rank: it only depends on the level's size): one exchange per doubling of the work beyond
+        GCRE_EXCHANGE_UNIT joined-path x 2048-permutation tiles per rank (default 2 M, about 0.3 ms of the pruned kernel),
+        at most 8.  Small joins do not exchange at all."""
+        if world <= 1 or self.problem.iterations <= 0:
+            return 0
+        unit = float(os.environ.get("GCRE_EXCHANGE_UNIT", 2e6))
+        window = self._window if self._window else self.problem.iterations
+        tiles = -(-min(window, self.problem.iterations) // 2048)
+        work = self.uids[name].total_paths / world * tiles
+        if unit <= 0 or work < 2 * unit:
+            return 0
+        return int(min(8, np.floor(np.log2(work / unit))))
+
     def run(self, rank: int = 0, world: int = 1, d_null_out: int = 0, on_level=None,
-            keep_inspections: bool = False) -> Dict[str, JoinResult]:
+            keep_inspections: bool = False, exchange=None) -> Dict[str, JoinResult]:
         """One pass over all levels.  Large permutation counts run in windows of whole 2048-permutation tiles (the count
         planes of the kept sets are per tile and have to fit in device memory): all levels for window 0, then all levels
         for window 1, ...  ``on_level(name, result, shard, window)`` sees every (level, window) result -- its null
@@ -714,7 +750,12 @@ class ResidentPlan:
         A pass of several windows runs every join's inspector (expansion, observed scores, top-k, kept rows, lists) for the
         first window only: the library's inspection cache is on for the pass, and forgotten when the next pass starts --
         unless ``keep_inspections``: then a later pass over the same resident inputs starts every join at its null
-        kernel (steady state of a service that re-scores the same network against new permutations)."""
+        kernel (steady state of a service that re-scores the same network against new permutations).
+
+        ``exchange(name, k0, k1)`` (multi-GPU): MAX-all-reduce ``d_null_out[k0:k1]`` across the ranks in place; called
+        ``exchange_count(name, world)`` times during a level's join so that every rank prunes against the whole level's
+        running maxima, not only its shard's (gcre_join_opts.exchange).  The null maxima a rank then returns include what
+        it learned from the others; their MAX over the ranks is unchanged."""
         K = self.problem.iterations
         if self._window is None:
             self._window = self.planned_window()
@@ -736,9 +777,11 @@ class ResidentPlan:
             for name in self.names:
                 p0, p1, res = self.operands(name)
                 b, e = self.shard(name, rank, world)
+                n_ex = self.exchange_count(name, world) if (exchange is not None and d_null_out) else 0
                 r = self.ex.join(self.uids[name], p0, p1, res, shard=(b, e) if world > 1 else None,
                                  d_null_out=(d_null_out + 4 * k0) if d_null_out else 0,
-                                 keep=self.needed_rows(name, rank, world), keep_mode=self.keep_mode(name))
+                                 keep=self.needed_rows(name, rank, world), keep_mode=self.keep_mode(name),
+                                 exchange=(lambda a, b_, name=name: exchange(name, a, b_)) if n_ex else None, exchanges=n_ex)
                 for k, v in self.ex.profile().items():
                     prof[k] = prof.get(k, 0) + v
                 if on_level is not None:

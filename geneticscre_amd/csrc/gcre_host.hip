@@ -154,6 +154,7 @@ struct gcre_ctx {
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
   int ie_quad = 1;                   // GCRE_IE_QUAD=0: the pruned method-1 launches stay on k_null_ie_m1 (cross-check)
+  int ie_warm_items = 4;             // (segment, tile) items per wave of the warm-up launch (GCRE_IE_WARM_ITEMS)
   int ie_warm_segs = 2048;           // least number of segments in the warm-up slice (GCRE_IE_WARM)
   int ie_small_join_tiles = 8;       // GCRE_IE_SJT (tuning)
   int ie_batch = 2;                  // segments per ticket (GCRE_IE_BATCH)
@@ -844,6 +845,24 @@ struct JoinPlan {
   bool keep_ranged = false;        // rows outside [keep_begin, keep_end) and the shard are not produced at all
   bool planes_ranged = false;      // every row is produced, count planes only for [keep_begin, keep_end) and the shard
   int64_t keep_begin = 0, keep_end = 0;
+  // thresholds shared with the other devices during the join (gcre_join_opts.exchange)
+  int exchanges = 0;
+  int (*exchange)(void*, void*, int32_t, int32_t) = nullptr;
+  void* exchange_user = nullptr;
+  void take(const gcre_join_opts* o) {
+    if (!o) return;
+    if (o->keep_ranged) {
+      keep_ranged = o->keep_ranged == 1;
+      planes_ranged = o->keep_ranged == 2;
+      keep_begin = o->keep_begin;
+      keep_end = o->keep_end;
+    }
+    if (o->exchange && o->exchanges > 0 && o->d_null_out) {
+      exchanges = o->exchanges;
+      exchange = o->exchange;
+      exchange_user = o->exchange_user;
+    }
+  }
 };
 
 void free_uids(gcre_uids* u) {
@@ -1061,6 +1080,20 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   if (Kpad > 0) HIP_TRY(c, hipMemsetAsync(w_null, 0, (size_t)Kpad * 4, st));
 
   const NullConfig cfg = null_config(g.method, g.K);
+  // ---- thresholds shared across devices: the maxima so far go out, the merged ones come back (gcre_join_opts.exchange) ----
+  int exchanges_done = 0;
+  auto exchange_now = [&]() -> int {
+    if (!jp.exchange || exchanges_done >= jp.exchanges) return GCRE_OK;
+    exchanges_done++;
+    if (g.K <= 0) return GCRE_OK;
+    HIP_TRY(c, hipMemcpyAsync(jp.d_null_out, w_null, (size_t)g.K * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (jp.exchange(jp.exchange_user, jp.d_null_out, c->win_k0, c->win_k0 + g.K) != 0)
+      return fail(c, GCRE_ERR_DEVICE, "the caller's threshold exchange failed");
+    // merged maxima are >= this shard's: a plain copy back (non-negative floats order like their bit patterns)
+    HIP_TRY(c, hipMemcpyAsync(w_null, jp.d_null_out, (size_t)g.K * 4, hipMemcpyDeviceToDevice, st));
+    return GCRE_OK;
+  };
   std::vector<Candidate> cands;
   c->prof = gcre_profile{};
   double select_ms = 0, select_wait_ms = 0;
@@ -1593,11 +1626,14 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             const int64_t warm_min = std::max<int64_t>(256, (int64_t)c->ie_warm_segs * 8 / std::max(nkt_sp, 8));
             int64_t n_warm = std::min<int64_t>(nseg_scored, std::min<int64_t>(std::max<int64_t>(warm_min, nseg_scored / 1024),
                                                                               std::max<int64_t>(256, nseg_scored / 8)));
+            // maxima shared with the other devices right after the warm-up: every device warms its share of the slice
+            if (jp.exchange && exchanges_done < jp.exchanges && P > 0)
+              n_warm = std::min(n_warm, std::max<int64_t>(64, (int64_t)((double)n_warm * (double)(se - sb) / (double)P) + 1));
             if (c->ie_warm_segs == 0) n_warm = 0;   // GCRE_IE_WARM=0 (tests): everything through the pruned kernel, thresholds from 0
             IeArgs wa = ia;
             wa.seg_end = n_warm;
             // a wave walks its tiles one after the other: keep enough waves that each gets about four (segment, tile) items
-            while (wa.waves_per_xcd > 4 && n_warm * nkt_sp < (int64_t)8 * wa.waves_per_xcd * 4)
+            while (wa.waves_per_xcd > 4 && n_warm * nkt_sp < (int64_t)8 * wa.waves_per_xcd * c->ie_warm_items)
               wa.waves_per_xcd = std::max(4, (wa.waves_per_xcd / 2 / 4) * 4);
             if (n_warm > 0) HIP_TRY(c, launch_null_ie(wa, g.method, planes, true, st));
             ia.seg_begin = n_warm;
@@ -1629,9 +1665,26 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             }
             // tickets are 32-bit: (batches per tile) x tiles must stay below 2^32
             while (((ia.nsegs - ia.seg_begin) / ia.batch + 1) * (int64_t)ia.nkt > (int64_t)0xf0000000ll) ia.batch *= 2;
-            HIP_TRY(c, hipMemsetAsync(ia.queue, 0, 8 * 16 * 4, st));
-            if (quad) HIP_TRY(c, launch_null_ie_quad(ia, planes, st));
-            else HIP_TRY(c, launch_null_ie(ia, g.method, planes, c->d_ladder == nullptr, st));
+            // One launch -- or, when the maxima are shared with other devices as the join goes (gcre_join_opts.exchange),
+            // E slices 1/2^(E-1), .., 1/4, 1/2 of the range with an exchange before each: the thresholds of a shard then
+            // follow the whole level's maxima (the maximum over n paths grows like log n: early exchanges matter most).
+            const bool pruned = c->d_ladder && ia.lad_mode == 0;
+            const int n_slices = (pruned && jp.exchange) ? std::max(1, jp.exchanges - exchanges_done) : 1;
+            const int64_t r_b = quad ? ia.quad_begin : ia.seg_begin, r_e = quad ? ia.quad_end : ia.seg_end;
+            int64_t lo = r_b;
+            for (int sl = 0; sl < n_slices && lo < r_e; sl++) {
+              int64_t hi = r_e;
+              if (sl + 1 < n_slices) hi = std::min(r_e, std::max(lo + 1, r_b + ((r_e - r_b) >> (n_slices - 1 - sl))));
+              if (pruned && jp.exchange)
+                if (int rc = exchange_now()) return rc;
+              IeArgs sa2 = ia;
+              if (quad) { sa2.quad_begin = lo; sa2.quad_end = hi; }
+              else { sa2.seg_begin = lo; sa2.seg_end = hi; }
+              HIP_TRY(c, hipMemsetAsync(sa2.queue, 0, 8 * 16 * 4, st));
+              if (quad) HIP_TRY(c, launch_null_ie_quad(sa2, planes, st));
+              else HIP_TRY(c, launch_null_ie(sa2, g.method, planes, c->d_ladder == nullptr, st));
+              lo = hi;
+            }
             if (quad) c->prof.ie_quad_launches++;
             ie_quad_ran = quad;
           }
@@ -1842,6 +1895,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     jp.res->max_known = true;
   }
 
+  // a join that took another road (small, unpruned, another kernel form) still makes the calls the other devices expect
+  while (jp.exchange && exchanges_done < jp.exchanges)
+    if (int rc = exchange_now()) return rc;
+
   // ---- null maxima: first K entries, f32 (methods.h:101-102; format_result, join_base.cpp:144-146) ----
   out->n_perm = g.K;
   out->null_max = (float*)std::calloc((size_t)std::max(g.K, 1), sizeof(float));
@@ -1947,6 +2004,7 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
     c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : !std::strcmp(e, "ie") ? 3 : 0;
   if (const char* e = std::getenv("GCRE_IE_PRUNE")) c->ie_prune = std::atoi(e) != 0;
   if (const char* e = std::getenv("GCRE_IE_WARM")) c->ie_warm_segs = std::min(std::max(std::atoi(e), 0), 1 << 20);
+  if (const char* e = std::getenv("GCRE_IE_WARM_ITEMS")) c->ie_warm_items = std::min(std::max(std::atoi(e), 1), 64);
   if (const char* e = std::getenv("GCRE_IE_SJT")) c->ie_small_join_tiles = std::atoi(e);
   if (const char* e = std::getenv("GCRE_IE_BATCH")) c->ie_batch = std::min(std::max(std::atoi(e), 1), 4096);
   if (const char* e = std::getenv("GCRE_IE_QUAD")) c->ie_quad = std::min(std::max(std::atoi(e), 0), 2);   // 2: wherever it can run
@@ -2351,12 +2409,7 @@ int gcre_join(gcre_ctx* c, int path_length, const int32_t* uid_count, const int6
   if (!u) return c->last_code;
   JoinPlan jp{u, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
               opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
-  if (opts && opts->keep_ranged) {
-    jp.keep_ranged = opts->keep_ranged == 1;
-    jp.planes_ranged = opts->keep_ranged == 2;
-    jp.keep_begin = opts->keep_begin;
-    jp.keep_end = opts->keep_end;
-  }
+  jp.take(opts);
   int rc = run_join(c, jp, out);
   free_uids(u);
   if (rc != GCRE_OK) gcre_result_free(out);
@@ -2411,12 +2464,7 @@ int gcre_join_uids(gcre_ctx* c, const gcre_uids* uids, const gcre_pathset* paths
   (void)hipSetDevice(c->device);
   JoinPlan jp{uids, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
               opts ? opts->shard_end : 0, opts ? opts->d_null_out : nullptr};
-  if (opts && opts->keep_ranged) {
-    jp.keep_ranged = opts->keep_ranged == 1;
-    jp.planes_ranged = opts->keep_ranged == 2;
-    jp.keep_begin = opts->keep_begin;
-    jp.keep_end = opts->keep_end;
-  }
+  jp.take(opts);
   int rc = run_join(c, jp, out);
   if (rc != GCRE_OK) gcre_result_free(out);
   return rc;

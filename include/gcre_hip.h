@@ -64,6 +64,18 @@ typedef struct {
                            (for an RCCL MAX all-reduce by the caller); may be NULL */
   int64_t keep_begin;   /* joined-path ordinals = rows of `res` (see keep_ranged) */
   int64_t keep_end;
+  /* Multi-device runs: a shard prunes its table look-ups against the running per-permutation maxima (the reference's
+   * `perm_scores[r] = max(...)`, src/methods.h:101-102, is what they bound), and a device that sees 1/N of the paths
+   * knows lower maxima than the whole level has.  When `exchange` is set the join calls it exactly `exchanges` times --
+   * after the warm-up slice and between the slices (1/2^(E-1), .., 1/4, 1/2 of the shard) of its permutation kernel --
+   * with the device buffer d_null_out holding this shard's maxima of permutations [k0, k1) so far (floats, >= 0); the
+   * callee MAX-all-reduces them in place across the devices (RCCL) and returns 0 once the buffer may be read; the join
+   * goes on with the merged maxima as thresholds.  Every device must pass the same `exchanges`; a join that takes another
+   * kernel form still makes its calls, so that the collectives match up.  Results do not depend on it.  d_null_out is
+   * required. */
+  int32_t exchanges;
+  int (*exchange)(void* user, void* d_null, int32_t k0, int32_t k1);
+  void* exchange_user;
 } gcre_join_opts;
 
 /* Timing of the last join / process_paths call, measured with HIP events on the library's stream. */

@@ -6,7 +6,7 @@ import bench
 from geneticscre_amd import api
 
 rank, world = int(sys.argv[1]), int(sys.argv[2])
-cfg = dict(bench.CONFIGS["roofline"])
+cfg = dict(bench.CONFIGS[os.environ.get("CONFIG", "roofline")])
 if os.environ.get("WEAK") == "1":      # weak scaling: 10,000 permutations per rank
     cfg["perms"] *= world
 prob, masks = bench.build_inputs(cfg, 20261003, 100)
