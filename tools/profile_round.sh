@@ -10,7 +10,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/prof/tcc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state > /dev/null 2>&1 || exit 1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d gpurun_out/prof/sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state > /dev/null 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/prof/sq2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state > /dev/null 2>&1 || exit 1
-python3 bench.py --steps 3 --warmup 1 > gpurun_out/prof/bench.json 2> gpurun_out/prof/bench.err || exit 1
 python3 - "$TAG" "$HEAD_SHA" <<'PY'
 import csv, glob, collections, json, sys, shutil
 tag, head = sys.argv[1], sys.argv[2]
@@ -36,14 +35,16 @@ launches = 5   # joins per pass: every join is one null "launch" in bench.py's a
 out["null_kernels"] = null
 out["traffic_bytes_per_null_launch"] = (2 * fetch + write) / launches
 out["fetch_bytes_raw"], out["write_bytes_raw"] = fetch, write
-b = json.load(open("gpurun_out/prof/bench.json"))
+b = json.loads(open("gpurun_out/prof/bench_kt.json").read().strip().splitlines()[-1])
 K = b["config"]["permutations_total"]
 out["path_tiles"] = sum(b["config"]["paths_per_level"].values()) * ((K + 2047) // 2048)
 json.dump(out, open(f"gpurun_out/prof/{tag}_pmc.json", "w"), indent=1)
+shutil.copy(f"gpurun_out/prof/{tag}_pmc.json", f"profiles/{tag}_pmc.json")   # the bench line below reads the newest one
 f = glob.glob("gpurun_out/prof/kt/**/*kernel_stats.csv", recursive=True)[0]
 shutil.copy(f, f"gpurun_out/prof/{tag}_kernel_stats_roofline_steps2.csv")
-shutil.copy("gpurun_out/prof/bench.json", f"gpurun_out/prof/{tag}_bench_roofline.json")
-print(open("gpurun_out/prof/bench.json").read()[:1500])
 for r in list(csv.DictReader(open(f)))[:8]:
     print(f"{r['Name'][:60]:60s} calls {r['Calls']:>5s} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} avg_ms {float(r['AverageNs'])/1e6:8.3f}")
 PY
+# the full default line (cpu_baseline, end_to_end, steady_state), with this run's counters behind roofline.traffic / .valu
+python3 bench.py --steps 3 --warmup 1 > gpurun_out/prof/${TAG}_bench_roofline.json 2> gpurun_out/prof/bench.err || exit 1
+head -c 1500 gpurun_out/prof/${TAG}_bench_roofline.json
