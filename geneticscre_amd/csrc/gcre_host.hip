@@ -28,6 +28,19 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// GCRE_POISON (diagnostics): count-plane buffers handed to a set start as 0x5A bytes instead of whatever was there, so
+// that a read of rows nobody wrote shows in the results of a fresh process too (planes are data, never indices)
+inline bool poison_fresh_planes() {
+  static const bool on = std::getenv("GCRE_POISON") != nullptr && std::atoi(std::getenv("GCRE_POISON")) != 0;
+  return on;
+}
+inline void poison_planes(void* p, size_t bytes) {
+  if (!poison_fresh_planes() || !p) return;
+  (void)hipDeviceSynchronize();
+  (void)hipMemset(p, 0x5A, bytes);
+  (void)hipDeviceSynchronize();
+}
+
 template <typename T>
 struct DevBuf {   // grow-only device scratch
   T* p = nullptr;
@@ -82,6 +95,7 @@ struct Winners {
 // permutation window of the same join starts at the null kernel.
 struct ChunkInsp {
   int64_t cb = -1, n = 0, s0 = 0, s1 = 0;
+  int64_t padded = 0;         // rows / totals are zero up to here (whole path tiles of the dense kernel)
   bool inspected = false;     // rows / statistics / keys (and kept rows) are those of this chunk
   bool with_lists = false;    // ... written by the inclusion-exclusion inspector: lists, rowz, linfo
   bool in_recipe = false;     // ... into the kept set's recipe (not into the buffers below)
@@ -138,6 +152,12 @@ struct gcre_ctx {
   int device = 0;
   int top_k = 12;   // JoinExec::top_k, gcre.h:120
   hipStream_t stream = nullptr;
+  // the top-k selection of a chunk only reads the keys its inspector wrote: it runs beside the warm-up slice and the
+  // null kernel on a stream of its own (GCRE_SELECT_STREAM=0: on the main stream, as in round 1)
+  hipStream_t sel_stream = nullptr;
+  hipEvent_t ev_sel = nullptr;
+  bool sel_async = true;
+  SelectState h_sel{};               // where the digit passes' state lands (outlives any one chunk: the copy is asynchronous)
   std::string err;
   int last_code = GCRE_OK;
   bool quiet = false;
@@ -532,6 +552,7 @@ bool alloc_planes(gcre_ctx* c, const gcre_pathset* ps, int groups) {
   if (ps->d_planes && ps->planes_bytes >= bytes) {   // its own buffer is large enough (another window, other groups)
     ps->plane_groups = groups;
     ps->planes_valid = false;
+    poison_planes(ps->d_planes, ps->planes_bytes);
     return true;
   }
   drop_planes(ps);
@@ -561,6 +582,7 @@ bool alloc_planes(gcre_ctx* c, const gcre_pathset* ps, int groups) {
     }
     ps->planes_bytes = bytes;
   }
+  poison_planes(ps->d_planes, ps->planes_bytes);
   ps->plane_groups = groups;
   return true;
 }
@@ -773,18 +795,18 @@ int ensure_quads(gcre_ctx* c, const gcre_uids& u, gcre_uids::SegCache& sc, int64
 // Two halves, so that a caller with a read-back of its own (the inspector's flags) can fold the state's into it:
 // select_begin queues the eight digit passes (one read-back of the state they leave, gcre_kernels.hip) and the copy
 // of that state into *hs; select_finish -- after a stream synchronisation -- queues the collection of the winners.
-int select_begin(gcre_ctx* c, int64_t first, int64_t count, int k, SelectState* hs) {
+int select_begin(gcre_ctx* c, int64_t first, int64_t count, int k, SelectState* hs, hipStream_t sst) {
   *hs = SelectState{};
   if (count == 0 || k <= 0) return GCRE_OK;
   HIP_TRY(c, c->d_small.reserve(512));
   HIP_TRY(c, c->d_sel.reserve((size_t)k + 64));
   SelectState* d_state = (SelectState*)(c->d_small.p + 264);
-  HIP_TRY(c, launch_radix_select(c->d_key.p + first, count, std::min<int64_t>(k, count), c->d_small.p, d_state, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(hs, d_state, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, launch_radix_select(c->d_key.p + first, count, std::min<int64_t>(k, count), c->d_small.p, d_state, sst));
+  HIP_TRY(c, hipMemcpyAsync(hs, d_state, sizeof *hs, hipMemcpyDeviceToHost, sst));
   return GCRE_OK;
 }
 
-int select_finish(gcre_ctx* c, int64_t first, int64_t count, int k, const SelectState& hs, uint32_t* n_selected) {
+int select_finish(gcre_ctx* c, int64_t first, int64_t count, int k, const SelectState& hs, uint32_t* n_selected, hipStream_t sst) {
   *n_selected = 0;
   if (count == 0 || k <= 0) return GCRE_OK;
   uint32_t* d_counter = c->d_small.p + 256;
@@ -793,45 +815,45 @@ int select_finish(gcre_ctx* c, int64_t first, int64_t count, int k, const Select
   const int64_t need = hs.need, greater = hs.greater;
   const uint32_t eq_count = hs.eq_count;
   const uint64_t T = prefix;   // the need-th largest key overall
-  HIP_TRY(c, hipMemsetAsync(d_counter, 0, sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(d_counter, 0, sizeof(uint32_t), sst));
   uint32_t nsel = 0;
   if (T == 0) {
     // fewer scorable paths than k: everything with a real score is selected
-    HIP_TRY(c, launch_collect_gt(key, count, 0, c->d_sel.p, d_counter, (uint32_t)k, c->stream));
+    HIP_TRY(c, launch_collect_gt(key, count, 0, c->d_sel.p, d_counter, (uint32_t)k, sst));
     nsel = (uint32_t)greater;
   } else if ((int64_t)eq_count == need) {
     // every path that ties with the threshold is wanted: no cut needed
-    HIP_TRY(c, launch_collect_gt(key, count, T - 1, c->d_sel.p, d_counter, (uint32_t)k, c->stream));
+    HIP_TRY(c, launch_collect_gt(key, count, T - 1, c->d_sel.p, d_counter, (uint32_t)k, sst));
     nsel = (uint32_t)(greater + need);
   } else {
     // ties at the threshold exceed the remaining slots: keep the `need` smallest ordinals
-    HIP_TRY(c, launch_collect_gt(key, count, T, c->d_sel.p, d_counter, (uint32_t)k, c->stream));
+    HIP_TRY(c, launch_collect_gt(key, count, T, c->d_sel.p, d_counter, (uint32_t)k, sst));
     const int64_t chunks = (count + 1023) / 1024;
     HIP_TRY(c, c->d_chunk.reserve((size_t)chunks));
-    HIP_TRY(c, launch_eq_count(key, count, T, c->d_chunk.p, c->stream));
+    HIP_TRY(c, launch_eq_count(key, count, T, c->d_chunk.p, sst));
     std::vector<uint32_t> cnt((size_t)chunks);
-    HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_chunk.p, cnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_chunk.p, cnt.size() * 4, hipMemcpyDeviceToHost, sst));
+    HIP_TRY(c, hipStreamSynchronize(sst));
     uint32_t run = 0;
     for (auto& v : cnt) {
       const uint32_t t = v;
       v = run;
       run += t;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->d_chunk.p, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, launch_eq_collect(key, count, T, c->d_chunk.p, (uint32_t)need, c->d_sel.p + greater, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // cnt must outlive the copy
+    HIP_TRY(c, hipMemcpyAsync(c->d_chunk.p, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, sst));
+    HIP_TRY(c, launch_eq_collect(key, count, T, c->d_chunk.p, (uint32_t)need, c->d_sel.p + greater, sst));
+    HIP_TRY(c, hipStreamSynchronize(sst));   // cnt must outlive the copy
     nsel = (uint32_t)(greater + need);
   }
   *n_selected = nsel;
   return GCRE_OK;
 }
 
-int select_chunk(gcre_ctx* c, int64_t first, int64_t count, int k, uint32_t* n_selected) {
+int select_chunk(gcre_ctx* c, int64_t first, int64_t count, int k, uint32_t* n_selected, hipStream_t sst) {
   SelectState hs{};
-  if (int rc = select_begin(c, first, count, k, &hs)) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return select_finish(c, first, count, k, hs, n_selected);
+  if (int rc = select_begin(c, first, count, k, &hs, sst)) return rc;
+  HIP_TRY(c, hipStreamSynchronize(sst));
+  return select_finish(c, first, count, k, hs, n_selected, sst);
 }
 
 struct JoinPlan {
@@ -1287,7 +1309,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       }
     }
     c->prof.prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
-    auto queue_winners = [&](int64_t s0, uint32_t nsel, Winners& w) -> int {
+    auto queue_winners = [&](int64_t s0, uint32_t nsel, Winners& w, hipStream_t qs) -> int {
       w.n = nsel;
       if (nsel == 0) return GCRE_OK;
       HIP_TRY(c, c->d_wkey.reserve(nsel));
@@ -1297,14 +1319,14 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       HIP_TRY(c, c->d_wrow1.reserve(nsel));
       HIP_TRY(c, launch_gather_winners(c->d_sel.p, nsel, c->d_key.p + s0, c->d_cases.p + s0, c->d_ctrls.p + s0,
                                        c->d_row0.p + s0, c->d_row1.p + s0, c->d_wkey.p, c->d_wcases.p, c->d_wctrls.p, c->d_wrow0.p,
-                                       c->d_wrow1.p, st));
+                                       c->d_wrow1.p, qs));
       w.sel.resize(nsel); w.cases.resize(nsel); w.ctrls.resize(nsel); w.r0.resize(nsel); w.r1.resize(nsel); w.key.resize(nsel);
-      HIP_TRY(c, hipMemcpyAsync(w.sel.data(), c->d_sel.p, nsel * 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipMemcpyAsync(w.key.data(), c->d_wkey.p, nsel * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipMemcpyAsync(w.cases.data(), c->d_wcases.p, nsel * 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipMemcpyAsync(w.ctrls.data(), c->d_wctrls.p, nsel * 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipMemcpyAsync(w.r0.data(), c->d_wrow0.p, nsel * 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipMemcpyAsync(w.r1.data(), c->d_wrow1.p, nsel * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(w.sel.data(), c->d_sel.p, nsel * 4, hipMemcpyDeviceToHost, qs));
+      HIP_TRY(c, hipMemcpyAsync(w.key.data(), c->d_wkey.p, nsel * 8, hipMemcpyDeviceToHost, qs));
+      HIP_TRY(c, hipMemcpyAsync(w.cases.data(), c->d_wcases.p, nsel * 4, hipMemcpyDeviceToHost, qs));
+      HIP_TRY(c, hipMemcpyAsync(w.ctrls.data(), c->d_wctrls.p, nsel * 4, hipMemcpyDeviceToHost, qs));
+      HIP_TRY(c, hipMemcpyAsync(w.r0.data(), c->d_wrow0.p, nsel * 4, hipMemcpyDeviceToHost, qs));
+      HIP_TRY(c, hipMemcpyAsync(w.r1.data(), c->d_wrow1.p, nsel * 4, hipMemcpyDeviceToHost, qs));
       return GCRE_OK;
     };
     // only the inclusion-exclusion kernels score part of a chunk; every other form gets chunks cut at the shard's ends
@@ -1322,8 +1344,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         const int64_t s1 = std::max(s0, std::min(std::max<int64_t>(sg.se - cb, 0), n));
         const bool scored = s1 > s0;
         const bool partial = scored && (s0 > 0 || s1 < n);
-        SelectState sel_state{};
+        SelectState& sel_state = c->h_sel;
         bool sel_begun = false, sel_done = false;
+        hipStream_t sel_on = st;   // the stream this chunk's selection runs on
         Winners win;
         const int64_t npt = (n + tile - 1) / tile;
         const int64_t padded = npt * tile;
@@ -1345,20 +1368,25 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ci->s1 = s1;
         }
         InspSwap swapped(c, ci);
-        HIP_TRY(c, c->d_row0.reserve(cap));
-        HIP_TRY(c, c->d_row1.reserve(cap));
-        HIP_TRY(c, c->d_tot.reserve(cap * g.method));
-        HIP_TRY(c, c->d_cases.reserve(cap));
-        HIP_TRY(c, c->d_ctrls.reserve(cap));
-        HIP_TRY(c, c->d_key.reserve(cap));
         const bool use_ie_chunk = want_ie && (scored || res_planes || rcp != nullptr);
         // replayed: the inspector's output is in place (rows, statistics, keys, kept rows, lists when this chunk wants them)
         const bool hit = ci && replay && ci->inspected &&
                          (!use_ie_chunk || (ci->with_lists && ci->flags_valid && ci->in_recipe == (rcp != nullptr)));
         if (ci && !hit) ci->inspected = ci->with_lists = ci->flags_valid = ci->win_valid = false;
         if (hit) c->prof.inspect_replays++;
+        // room for this chunk.  A replayed chunk's buffers hold what its inspector wrote: they may only grow with their
+        // contents (the path tile, and with it `cap` and the padding below, depends on the window's permutation count)
+        auto hold = [&](auto& buf, size_t want) -> hipError_t { return hit ? buf.grow_keep(want, buf.cap, st) : buf.reserve(want); };
+        HIP_TRY(c, hold(c->d_row0, cap));
+        HIP_TRY(c, hold(c->d_row1, cap));
+        HIP_TRY(c, hold(c->d_tot, cap * g.method));
+        HIP_TRY(c, hold(c->d_cases, cap));
+        HIP_TRY(c, hold(c->d_ctrls, cap));
+        HIP_TRY(c, hold(c->d_key, cap));
         // the null kernel reads whole tiles: rows / totals beyond n must be valid (row 0, zero carriers)
-        if (padded > n && !hit) {
+        const bool pad_now = padded > n && (!hit || padded > ci->padded);
+        if (ci) ci->padded = std::max(hit ? ci->padded : (int64_t)0, padded);
+        if (pad_now) {
           HIP_TRY(c, hipMemsetAsync(c->d_row0.p + n, 0, (size_t)(padded - n) * 4, st));
           HIP_TRY(c, hipMemsetAsync(c->d_row1.p + n, 0, (size_t)(padded - n) * 4, st));
           HIP_TRY(c, hipMemsetAsync(c->d_tot.p + (size_t)n * g.method, 0, (size_t)(padded - n) * 4 * g.method, st));
@@ -1400,19 +1428,19 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, (rcp && recipe_started) ? 16 : 24, st));   // words 6, 7: the join's
           recipe_started = recipe_started || rcp != nullptr;
           sa.max_tot = c->d_max_tot;
-          HIP_TRY(c, c->d_dcnt.reserve((size_t)n * g.method));
+          HIP_TRY(c, hold(c->d_dcnt, (size_t)n * g.method));
           sa.dcnt = c->d_dcnt.p;
         }
         if (use_ie) {
           // one pass: statistics, kept rows, the check of the reduced operand, and the lists the null kernel streams
           const size_t nl = (size_t)n * g.method;
-          HIP_TRY(c, c->d_rowz.reserve(cap));
-          HIP_TRY(c, c->d_linfo.reserve(nl));
-          HIP_TRY(c, c->d_lover.reserve(nl));
-          HIP_TRY(c, c->d_dlist.reserve(nl * 8 + 16));
+          HIP_TRY(c, hold(c->d_rowz, cap));
+          HIP_TRY(c, hold(c->d_linfo, nl));
+          HIP_TRY(c, hold(c->d_lover, nl));
+          HIP_TRY(c, hold(c->d_dlist, nl * 8 + 16));
           // + the waves' chunk slack: every wave of the inspector may leave most of a 2048-entry reservation unused
           const size_t over_slack = (std::min<size_t>(16384, ((size_t)n + 15) / 16 * 4) + 2) * 2048;
-          HIP_TRY(c, c->d_dover.reserve(std::max<size_t>(c->d_dover.cap, nl * 2 + over_slack)));
+          HIP_TRY(c, hold(c->d_dover, std::max<size_t>(c->d_dover.cap, nl * 2 + over_slack)));
           sa.pz = red->d_rows;
           sa.zindex = hinted ? u.d_red_index : nullptr;
           sa.excess = hinted ? c->d_excess.p : nullptr;
@@ -1460,7 +1488,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         // the top-k selection only needs the keys the inspector just wrote: its digit passes run now, their state
         // comes back with the inspector's flags, its winners are collected before the null kernel starts
         if (use_ie && g.K > 0 && scored && !sel_done) {
-          if (int rc = select_begin(c, s0, s1 - s0, c->top_k, &sel_state)) return rc;
+          if (c->sel_async) {   // beside the warm-up slice and the null kernel, behind the inspector
+            HIP_TRY(c, hipEventRecord(c->ev_sel, st));
+            HIP_TRY(c, hipStreamWaitEvent(c->sel_stream, c->ev_sel, 0));
+            sel_on = c->sel_stream;
+          }
+          if (int rc = select_begin(c, s0, s1 - s0, c->top_k, &sel_state, sel_on)) return rc;
           sel_begun = true;
         }
         if (!scored && !(use_ie && g.K > 0)) continue;
@@ -1606,10 +1639,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             HIP_TRY(c, hipMemsetAsync(d_timing, 0, 64, st));
             ia.timing = d_timing;
           }
-          if (sel_begun && scored) {
+          if (sel_begun && scored && sel_on == st) {   // (its state came back with the flags)
             uint32_t nsel = 0;
-            if (int rc = select_finish(c, s0, s1 - s0, c->top_k, sel_state, &nsel)) return rc;
-            if (int rc = queue_winners(s0, nsel, win)) return rc;
+            if (int rc = select_finish(c, s0, s1 - s0, c->top_k, sel_state, &nsel, st)) return rc;
+            if (int rc = queue_winners(s0, nsel, win, st)) return rc;
             sel_done = true;
           }
           hipEvent_t n0 = get_event(c), n1 = get_event(c);
@@ -1689,6 +1722,15 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             ie_quad_ran = quad;
           }
           HIP_TRY(c, hipEventRecord(n1, st));
+          if (sel_begun && scored && !sel_done) {   // own stream: the digit passes ran beside the warm-up slice
+            const auto tw0 = std::chrono::steady_clock::now();
+            HIP_TRY(c, hipStreamSynchronize(sel_on));
+            select_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+            uint32_t nsel = 0;
+            if (int rc = select_finish(c, s0, s1 - s0, c->top_k, sel_state, &nsel, sel_on)) return rc;
+            if (int rc = queue_winners(s0, nsel, win, sel_on)) return rc;
+            sel_done = true;
+          }
           if (timing) {
             uint64_t tmv[8] = {0};
             HIP_TRY(c, hipMemcpyAsync(tmv, d_timing, 64, hipMemcpyDeviceToHost, st));
@@ -1754,6 +1796,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             const double dense_cost = 2.0 * g.Wp * g.method * (double)g.K * 2.0 / 65.0;
             if (sparse_cost >= dense_cost) break;   // dense kernel below
           }
+          if (ci) ci->with_lists = false;   // the delta lists below take the place of the inspector's
           HIP_TRY(c, c->d_dlist.reserve((size_t)n_delta + 16));
           HIP_TRY(c, launch_delta_fill((const uint32_t*)jp.p0->d_rows, 2 * g.S, 2 * g.Wp, g.method, c->d_row0.p,
                                        c->d_row1.p, n, jp.p1->d_loff, jp.p1->d_lidx, c->d_doff.p, zoff,
@@ -1840,12 +1883,19 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         const auto ts0 = std::chrono::steady_clock::now();
         if (!sel_done) {
           uint32_t nsel = 0;
-          int rc = select_chunk(c, s0, s1 - s0, c->top_k, &nsel);
-          if (rc != GCRE_OK) return rc;
-          if (int rc2 = queue_winners(s0, nsel, win)) return rc2;
+          if (sel_begun) {   // begun, then the chunk left the inclusion-exclusion road: its state is still good
+            HIP_TRY(c, hipStreamSynchronize(sel_on));
+            if (int rc = select_finish(c, s0, s1 - s0, c->top_k, sel_state, &nsel, sel_on)) return rc;
+          } else {
+            if (c->sel_stream) HIP_TRY(c, hipStreamSynchronize(c->sel_stream));   // an abandoned selection shares the scratch
+            int rc = select_chunk(c, s0, s1 - s0, c->top_k, &nsel, st);
+            if (rc != GCRE_OK) return rc;
+          }
+          if (int rc2 = queue_winners(s0, nsel, win, sel_on)) return rc2;
         }
         if (win.n > 0) {
           const auto tw0 = std::chrono::steady_clock::now();
+          if (sel_on != st) HIP_TRY(c, hipStreamSynchronize(sel_on));
           HIP_TRY(c, hipStreamSynchronize(st));   // the null kernel of this chunk: its time is not the selection's
           select_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
           for (uint32_t i = 0; i < win.n; i++)
@@ -2012,6 +2062,9 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));
 
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&c->sel_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) == hipSuccess;
+  if (const char* e = std::getenv("GCRE_SELECT_STREAM")) c->sel_async = std::atoi(e) != 0;
   ok = ok && hipMalloc((void**)&c->d_case_mask, (size_t)g.Wp * 8) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_max_tot, 32) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_queue, 8 * 16 * 4) == hipSuccess;
@@ -2066,6 +2119,9 @@ void gcre_destroy(gcre_ctx* c) {
   for (auto& pb : c->plane_pool) (void)hipFree(pb.p);
   c->plane_pool.clear();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->sel_stream) (void)hipStreamSynchronize(c->sel_stream);
+  if (c->sel_stream) (void)hipStreamDestroy(c->sel_stream);
+  if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -116,6 +116,27 @@ def test_a_new_value_table_or_top_k_invalidates_the_cache(monkeypatch):
         plan.close()
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_a_short_last_window_changes_the_path_tile_not_the_cached_rows(world, monkeypatch):
+    """K = 2300 in one-tile windows: the second window has 252 permutations, for which the dense kernel's path tile -- and
+    with it the padded size of every per-chunk buffer -- is larger.  A replayed chunk's buffers must grow with their
+    contents (they were once simply re-allocated: stale row numbers, a memory fault)."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_PLANES_OUT_MAX_MB", "0")
+    monkeypatch.setenv("GCRE_WINDOW_TILES", "1")
+    p = make_problem(70, 260, 310, 335, 2300, 5, method="method1", top_k=15, seed=14, threshold=0.05)
+    want = oracle.process_paths(p, order="canonical")
+    parts = []
+    for rank in range(world):
+        plan = api.ResidentPlan(p)
+        parts.append(plan.run(rank=rank, world=world))
+        assert plan.last_profile["inspect_replays"] == len(plan.names)
+        plan.close()
+    for name, lst in LEVELS:
+        null = np.maximum.reduce([r[name].null for r in parts])
+        np.testing.assert_array_equal(null.view(np.uint32), want[lst].null.view(np.uint32), err_msg=name)
+
+
 @pytest.mark.parametrize("chunk", ["256", "0"])
 def test_windows_of_sharded_chunked_joins_replay(chunk, monkeypatch):
     """Two ranks, joins cut into several chunks (GCRE_CHUNK_PATHS) and two-tile windows: every chunk of every join is
