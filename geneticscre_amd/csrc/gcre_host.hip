@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
+#include <condition_variable>
 #include <string>
 #include <unordered_map>
 #include <thread>
@@ -147,6 +149,45 @@ struct HostTimer {
 
 }  // namespace
 
+// gcre_process_paths_devices: the device threads of one call meet here to MAX-merge their running null maxima during a
+// join (gcre_join_opts.exchange, served inside the library).  K floats per call: the host does the reduction.
+struct ExchangeHub {
+  int n = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  bool failed = false;
+  std::vector<float> acc, result;
+  int reduce(std::vector<float>& mine) {   // in: this device's maxima; out: the MAX over all devices
+    std::unique_lock<std::mutex> lk(m);
+    if (failed) return 1;
+    if (arrived == 0) {
+      acc = mine;
+    } else {
+      if (acc.size() != mine.size()) { failed = true; cv.notify_all(); return 1; }
+      for (size_t i = 0; i < mine.size(); i++) acc[i] = std::max(acc[i], mine[i]);
+    }
+    if (++arrived == n) {
+      result.swap(acc);
+      arrived = 0;
+      gen++;
+      cv.notify_all();
+    } else {
+      const uint64_t g = gen;
+      cv.wait(lk, [&] { return gen != g || failed; });
+      if (gen == g) return 1;   // somebody failed before this round completed
+    }
+    mine = result;
+    return 0;
+  }
+  void fail() {
+    std::lock_guard<std::mutex> lk(m);
+    failed = true;
+    cv.notify_all();
+  }
+};
+
 struct gcre_ctx {
   Geometry g{};
   int device = 0;
@@ -188,6 +229,8 @@ struct gcre_ctx {
   uint64_t mask_epoch = 0;           // bumped whenever the permutation masks change: count planes are per epoch
   uint64_t obs_epoch = 0;            // bumped whenever the value table changes: observed scores (keys, winners) are per epoch
   bool insp_cache = false;           // gcre_set_inspect_cache: a join's inspector output stays with its join index
+  ExchangeHub* hub = nullptr;        // set by gcre_process_paths_devices for the duration of a call
+  DevBuf<float> d_hub_null;          // the maxima this device hands to the hub
   // permutation window [win_k0, win_k0 + win_K): what a join scores.  The whole range by default; gcre_set_perm_window
   // narrows it so that the count planes of the kept sets (one per 2048-permutation tile) fit in device memory
   int win_k0 = 0, win_K = 0;
@@ -2106,6 +2149,7 @@ void gcre_destroy(gcre_ctx* c) {
                   &c->d_rec_segs, &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})
     b->release();
   c->d_key.release();
+  c->d_hub_null.release();
   c->d_wkey.release();
   c->d_doff.release();
   c->d_scan.release();
@@ -2615,6 +2659,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
   // The join index of a level is uploaded once and serves every permutation window.
   gcre_uids* level_uids[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uids_to_free = level_uids;
+  int pp_window = 0;   // permutations per window, once it is known (below)
   auto join = [&](int plen, int lvi, const gcre_pathset* p0, const gcre_pathset* p1, gcre_pathset* res,
                   gcre_result* o, const gcre_pathset* red = nullptr, const int32_t* red_index = nullptr,
                   int64_t n_red = 0) -> int {
@@ -2634,6 +2679,26 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       jp.sharded = true;
       jp.shard_begin = u->total * in->shard_rank / in->shard_world;
       jp.shard_end = u->total * (in->shard_rank + 1) / in->shard_world;
+      if (c->hub && c->win_K > 0) {
+        // the devices of this call share their running maxima during the join: one exchange per doubling of a device's
+        // work beyond GCRE_EXCHANGE_UNIT path-tiles (as ResidentPlan.exchange_count; the same on every device)
+        double unit = 2e6;
+        if (const char* e = std::getenv("GCRE_EXCHANGE_UNIT")) unit = std::atof(e);
+        const double work = (double)u->total / in->shard_world * (double)((pp_window + kSparseTile - 1) / kSparseTile);
+        if (unit > 0 && work >= 2 * unit && c->d_hub_null.reserve((size_t)c->g.Kpad + 64) == hipSuccess) {
+          jp.exchanges = (int)std::min(8.0, std::floor(std::log2(work / unit)));
+          jp.d_null_out = c->d_hub_null.p;
+          jp.exchange_user = c;
+          jp.exchange = [](void* user, void* d_null, int32_t k0, int32_t k1) -> int {
+            gcre_ctx* cc = (gcre_ctx*)user;
+            std::vector<float> v((size_t)std::max(k1 - k0, 0));
+            if (v.empty()) return 0;
+            if (hipMemcpy(v.data(), d_null, v.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { cc->hub->fail(); return 1; }
+            if (cc->hub->reduce(v) != 0) return 1;
+            return hipMemcpy(d_null, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+          };
+        }
+      }
     }
     gcre_result tmp;
     int r = run_join(c, jp, &tmp);
@@ -2683,6 +2748,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       win = std::min(win, w * kSparseTile);
     }
   }
+  pp_window = std::max(1, std::min(win, std::max(Kall, 1)));
   std::vector<float> null_all[5];
   // several windows: the joins of the 2nd..nth window start at their null kernels (inspection cache; the operands below
   // are made once, so that every window joins the same sets)
@@ -2841,13 +2907,18 @@ int gcre_process_paths_devices(int method, int n_cases, int n_ctrls, int iterati
   }
   std::vector<std::array<gcre_result, 5>> part((size_t)N);
   std::vector<int> rcs((size_t)N, GCRE_OK);
+  ExchangeHub hub;   // where the device threads MAX-merge their running maxima during the large joins
+  hub.n = N;
   if (rc == GCRE_OK) {
     auto work = [&](int r) {
       gcre_pp_input mine = *in;
       mine.shard_rank = N > 1 ? r : 0;
       mine.shard_world = N > 1 ? N : 0;
       mine.window_perms = N > 1 ? window : in->window_perms;
+      ctx[(size_t)r]->hub = N > 1 ? &hub : nullptr;
       rcs[(size_t)r] = gcre_process_paths(ctx[(size_t)r], &mine, part[(size_t)r].data());
+      ctx[(size_t)r]->hub = nullptr;
+      if (rcs[(size_t)r] != GCRE_OK) hub.fail();   // nobody waits for a device that has given up
     };
     std::vector<std::thread> th;
     for (int r = 1; r < N; r++) th.emplace_back(work, r);
