@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <condition_variable>
 #include <string>
@@ -348,6 +349,18 @@ struct gcre_uids {
     uint32_t* d_quads = nullptr;
   };
   mutable std::vector<SegCache> seg_cache;
+  // A segment table (and its quads) built ahead of the join that will ask for it, by a helper thread that touches nothing
+  // but the host copies of the join index (gcre_process_paths: the last level's tables while the first levels run)
+  struct Prefetch {
+    int64_t first = 0, count = 0, score_b = 0, score_e = 0, plane_b = 0, plane_e = 0;
+    std::vector<SparseSeg> segs;
+    int64_t nscored = 0;
+    std::vector<uint32_t> quads;
+    int64_t q_warm = -1, quad_begin = 0;
+    bool ready = false, quads_ready = false, quads_for_table = false;
+    std::thread th;
+  };
+  mutable std::unique_ptr<Prefetch> prefetch;
   // inspection cache (gcre_set_inspect_cache): the inspector output of the last join that ran on this index, per chunk,
   // valid while the operands' rows, the kept set, the shard and the observed-score inputs are the same
   mutable std::deque<ChunkInsp> insp;
@@ -653,21 +666,10 @@ int ensure_planes(gcre_ctx* c, const gcre_pathset* ps) {
 // kSparseSegMax long, none straddling the scored range [score_b, score_e).  The scored segments come first
 // (*nscored of them); of the others only the paths inside [plane_b, plane_e) are listed (the rest need no count
 // planes).  Cached per uids object (the join index is resident input; repeated joins reuse it).
-int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t count, int64_t score_b, int64_t score_e,
-                    int64_t plane_b, int64_t plane_e, const SparseSeg** d_out, int64_t* nsegs, int64_t* nscored,
-                    gcre_uids::SegCache** entry = nullptr) {
-  plane_b = std::max(plane_b, first);
-  plane_e = std::min(plane_e, first + count);
-  for (auto& sc : u.seg_cache)
-    if (sc.first == first && sc.count == count && sc.score_b == score_b && sc.score_e == score_e && sc.plane_b == plane_b &&
-        sc.plane_e == plane_e) {
-      *d_out = sc.d_segs;
-      *nsegs = sc.nsegs;
-      *nscored = sc.nscored;
-      if (entry) *entry = &sc;
-      return GCRE_OK;
-    }
-  HostTimer ht("sparse_segments");
+// The host half of sparse_segments: the table itself (no device call: a helper thread may build it ahead of the join that
+// needs it, gcre_uids::prefetch_tables).
+void build_segments_host(const gcre_uids& u, int64_t first, int64_t count, int64_t score_b, int64_t score_e, int64_t plane_b,
+                         int64_t plane_e, std::vector<SparseSeg>& segs, int64_t* nscored_out) {
   const auto& pi = u.h_path_idx;
   const int64_t end = first + count;
   // uids whose joined paths reach into [first, end)
@@ -744,7 +746,7 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
   // Segments that join the same paths1 rows (all uids with the same pivot gene share `location`) run next to each
   // other: the waves of an XCD walk a contiguous window of this table, so the planes of those rows stay in its L2.
   // Any order gives the same maxima.
-  std::vector<SparseSeg> segs(n_part[0] + n_part[1]);
+  segs.assign(n_part[0] + n_part[1], SparseSeg{});
   size_t base = 0;
   for (int q = 0; q < 2; q++) {
     const size_t nq = n_part[q];
@@ -779,6 +781,74 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
     }
     base += nq;
   }
+  *nscored_out = (int64_t)n_scored;
+}
+
+// quads of a segment table (gcre_ieq.hip): runs of up to four consecutive segments with the same first joined row and
+// length, none straddling n_warm or nscored.  Host only.
+void build_quads_host(const gcre_uids& u, const std::vector<SparseSeg>& segs, int64_t first, int64_t nscored, int64_t n_warm,
+                      std::vector<uint32_t>& quads, int64_t* quad_begin_out) {
+  const auto& pi = u.h_path_idx;
+  const int64_t n = (int64_t)segs.size();
+  quads.clear();
+  quads.reserve((size_t)n / 3 + 16);
+  int64_t quad_begin = -1;
+  auto key_of = [&](const SparseSeg& x) { return u.h_location[x.row0] + ((int64_t)x.first + first - pi[x.row0]); };
+  int64_t i = 0;
+  while (i < n) {
+    if (i >= n_warm && quad_begin < 0) quad_begin = (int64_t)quads.size();
+    const int64_t stop = i < n_warm ? n_warm : (i < nscored ? nscored : n);
+    const int64_t k0 = key_of(segs[(size_t)i]);
+    const uint32_t n0 = segs[(size_t)i].n;
+    int64_t j = i + 1;
+    while (j < stop && j < i + 4 && segs[(size_t)j].n == n0 && key_of(segs[(size_t)j]) == k0) j++;
+    quads.push_back((uint32_t)i | ((uint32_t)(j - i - 1) << 30));
+    i = j;
+  }
+  if (quad_begin < 0) quad_begin = (int64_t)quads.size();
+  *quad_begin_out = quad_begin;
+}
+
+// segments of the warm-up slice of a pruned launch (run_join): the first n_warm scored segments are scored without pruning
+int64_t warm_segments(const gcre_ctx* c, int64_t nseg_scored, int nkt) {
+  if (c->ie_warm_segs == 0) return 0;   // GCRE_IE_WARM=0 (tests): everything through the pruned kernel, thresholds from 0
+  const int64_t warm_min = std::max<int64_t>(256, (int64_t)c->ie_warm_segs * 8 / std::max(nkt, 8));
+  return std::min<int64_t>(nseg_scored, std::min<int64_t>(std::max<int64_t>(warm_min, nseg_scored / 1024),
+                                                          std::max<int64_t>(256, nseg_scored / 8)));
+}
+
+int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t count, int64_t score_b, int64_t score_e,
+                    int64_t plane_b, int64_t plane_e, const SparseSeg** d_out, int64_t* nsegs, int64_t* nscored,
+                    gcre_uids::SegCache** entry = nullptr) {
+  plane_b = std::max(plane_b, first);
+  plane_e = std::min(plane_e, first + count);
+  for (auto& sc : u.seg_cache)
+    if (sc.first == first && sc.count == count && sc.score_b == score_b && sc.score_e == score_e && sc.plane_b == plane_b &&
+        sc.plane_e == plane_e) {
+      *d_out = sc.d_segs;
+      *nsegs = sc.nsegs;
+      *nscored = sc.nscored;
+      if (entry) *entry = &sc;
+      return GCRE_OK;
+    }
+  std::vector<SparseSeg> segs;
+  int64_t n_scored_i = 0;
+  gcre_uids::Prefetch* pf = u.prefetch.get();
+  if (pf && pf->th.joinable()) {   // a table being built ahead: wait for it, whichever table this call wants
+    HostTimer hw("prefetched tables: wait");
+    pf->th.join();
+  }
+  if (pf && pf->ready && pf->first == first && pf->count == count && pf->score_b == score_b && pf->score_e == score_e &&
+      pf->plane_b == plane_b && pf->plane_e == plane_e) {
+    segs.swap(pf->segs);
+    n_scored_i = pf->nscored;
+    pf->ready = false;
+    pf->quads_for_table = true;   // its quads belong to the table made now
+  } else {
+    HostTimer ht("sparse_segments");
+    build_segments_host(u, first, count, score_b, score_e, plane_b, plane_e, segs, &n_scored_i);
+  }
+  const size_t n_scored = (size_t)n_scored_i;
   SparseSeg* d = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d, std::max<size_t>(segs.size(), 1) * sizeof(SparseSeg)));
   if (!segs.empty())
@@ -803,26 +873,20 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
 // there) and at the end of the scored segments.  quad_begin = the first quad of the pruned launch.
 int ensure_quads(gcre_ctx* c, const gcre_uids& u, gcre_uids::SegCache& sc, int64_t n_warm) {
   if (sc.q_warm == n_warm && sc.d_quads) return GCRE_OK;
-  HostTimer ht("ensure_quads");
-  const auto& pi = u.h_path_idx;
   const int64_t n = (int64_t)sc.h_segs.size();
   if (n != sc.nsegs || n >= ((int64_t)1 << 30)) return GCRE_ERR_ARG;   // no host copy (or too many segments): the caller falls back
   std::vector<uint32_t> quads;
-  quads.reserve((size_t)n / 3 + 16);
-  int64_t quad_begin = -1;
-  auto key_of = [&](const SparseSeg& x) { return u.h_location[x.row0] + ((int64_t)x.first + sc.first - pi[x.row0]); };
-  int64_t i = 0;
-  while (i < n) {
-    if (i >= n_warm && quad_begin < 0) quad_begin = (int64_t)quads.size();
-    const int64_t stop = i < n_warm ? n_warm : (i < sc.nscored ? sc.nscored : n);
-    const int64_t k0 = key_of(sc.h_segs[(size_t)i]);
-    const uint32_t n0 = sc.h_segs[(size_t)i].n;
-    int64_t j = i + 1;
-    while (j < stop && j < i + 4 && sc.h_segs[(size_t)j].n == n0 && key_of(sc.h_segs[(size_t)j]) == k0) j++;
-    quads.push_back((uint32_t)i | ((uint32_t)(j - i - 1) << 30));
-    i = j;
+  int64_t quad_begin = 0;
+  gcre_uids::Prefetch* pf = u.prefetch.get();
+  if (pf && pf->quads_ready && pf->quads_for_table && pf->q_warm == n_warm && pf->first == sc.first && pf->count == sc.count &&
+      pf->score_b == sc.score_b && pf->score_e == sc.score_e && pf->plane_b == sc.plane_b && pf->plane_e == sc.plane_e) {
+    quads.swap(pf->quads);   // built ahead with the table
+    quad_begin = pf->quad_begin;
+    pf->quads_ready = false;
+  } else {
+    HostTimer ht("ensure_quads");
+    build_quads_host(u, sc.h_segs, sc.first, sc.nscored, n_warm, quads, &quad_begin);
   }
-  if (quad_begin < 0) quad_begin = (int64_t)quads.size();
   if (sc.d_quads) (void)hipFree(sc.d_quads);
   sc.d_quads = nullptr;
   HIP_TRY(c, hipMalloc((void**)&sc.d_quads, std::max<size_t>(quads.size(), 1) * 4));
@@ -945,6 +1009,7 @@ void free_uids(gcre_uids* u) {
     if (sc.d_quads) (void)hipFree(sc.d_quads);
   }
   for (auto& ci : u->insp) ci.release();
+  if (u->prefetch && u->prefetch->th.joinable()) u->prefetch->th.join();
   delete u;
 }
 
@@ -1699,9 +1764,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             // (the scored segments lead the table.)  The general kernel is several times slower per path: a short
             // shard gives it an eighth of its segments, not all of them.
             // every tile warms up on its own permutations: with many tiles the slice gets shorter (its cost is per tile)
-            const int64_t warm_min = std::max<int64_t>(256, (int64_t)c->ie_warm_segs * 8 / std::max(nkt_sp, 8));
-            int64_t n_warm = std::min<int64_t>(nseg_scored, std::min<int64_t>(std::max<int64_t>(warm_min, nseg_scored / 1024),
-                                                                              std::max<int64_t>(256, nseg_scored / 8)));
+            int64_t n_warm = warm_segments(c, nseg_scored, nkt_sp);
             // maxima shared with the other devices right after the warm-up: every device warms its share of the slice
             if (jp.exchange && exchanges_done < jp.exchanges && P > 0)
               n_warm = std::min(n_warm, std::max<int64_t>(64, (int64_t)((double)n_warm * (double)(se - sb) / (double)P) + 1));
@@ -2749,6 +2812,34 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     }
   }
   pp_window = std::max(1, std::min(win, std::max(Kall, 1)));
+  // The last level's segment table and quads (tens of milliseconds of host work at 2.5 M uids) depend on its join index
+  // only: a helper thread builds them while the first levels run (GCRE_PREFETCH_TABLES=0: built when the join asks)
+  if (L >= 3 && Kall > 0 && in->shard_world <= 1 && sparse_enabled(c) && (c->null_kernel == 0 || c->null_kernel == 3) &&
+      !(std::getenv("GCRE_PREFETCH_TABLES") && std::atoi(std::getenv("GCRE_PREFETCH_TABLES")) == 0)) {
+    const gcre_level& lv = in->level[L];
+    const int64_t P = total_paths(lv);
+    if (lv.n_uids > 100000 && P > 0 && P <= c->chunk_paths && !level_uids[L]) {
+      gcre_uids* u = make_uids(c, L, lv.uid_count, lv.uid_location, lv.n_uids, lv.signs, lv.n_signs);
+      if (!u) { cleanup(); return c->last_code; }
+      level_uids[L] = u;
+      u->prefetch.reset(new gcre_uids::Prefetch());
+      gcre_uids::Prefetch* pf = u->prefetch.get();
+      pf->first = 0; pf->count = P; pf->score_b = 0; pf->score_e = P; pf->plane_b = 0; pf->plane_e = P;
+      const int nkt = (pp_window + kSparseTile - 1) / kSparseTile;
+      const bool with_quads = c->g.method == 1 && c->ie_quad && c->d_ladder;
+      const gcre_ctx* cc = c;
+      pf->th = std::thread([u, pf, P, nkt, with_quads, cc]() {
+        HostTimer hb("prefetched tables: build (helper thread)");
+        build_segments_host(*u, 0, P, 0, P, 0, P, pf->segs, &pf->nscored);
+        pf->ready = true;
+        if (with_quads && (int64_t)pf->segs.size() < ((int64_t)1 << 30)) {
+          pf->q_warm = warm_segments(cc, pf->nscored, nkt);
+          build_quads_host(*u, pf->segs, 0, pf->nscored, pf->q_warm, pf->quads, &pf->quad_begin);
+          pf->quads_ready = true;
+        }
+      });
+    }
+  }
   std::vector<float> null_all[5];
   // several windows: the joins of the 2nd..nth window start at their null kernels (inspection cache; the operands below
   // are made once, so that every window joins the same sets)
