@@ -1864,22 +1864,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     double score_prev = 0.0;
     int pl_prev = -1;
     // the rows of the next four paths are requested while these four are worked on
+    // (consecutive joined paths mostly share their paths0 row -- one uid joins ~11 rows at level 4: a group that stays
+    // on the same row keeps its words, and when no group moves on the load is not issued at all)
     u64x2 nx[NL], nz[NL];
-    u32 n_rz = 0u, n_rng = kNoRange;
+#pragma unroll
+    for (int it = 0; it < NL; it++) nx[it] = nz[it] = u64x2{0, 0};
+    u32 n_rz = 0u, n_rng = kNoRange, n_r0 = 0xffffffffu;
     auto fetch_rows = [&](int it4n) {
       const int pln = it4n * 4 + grp;
       const u32 r0n = (u32)__builtin_amdgcn_ds_bpermute(pln << 2, (int)r0v);
       n_rz = (u32)__builtin_amdgcn_ds_bpermute(pln << 2, (int)zv) & 0x7fffffffu;
       n_rng = (u32)__builtin_amdgcn_ds_bpermute(pln << 2, (int)rngv);
+      const bool new_x = r0n != n_r0;
+      n_r0 = r0n;
       const u64* xn = a.p0 + (size_t)r0n * a.S;
       const u64* zn = a.pz + (size_t)n_rz * a.S;
 #pragma unroll
       for (int it = 0; it < NL; it++) {
         const int k = it * 32 + 2 * sl;
-        nx[it] = u64x2{0, 0};
-        nz[it] = u64x2{0, 0};
         if (k < Wp) {            // Wp is a multiple of 4: words k and k + 1 are both inside
-          nx[it] = *(const u64x2*)(xn + k);
+          if (new_x) nx[it] = *(const u64x2*)(xn + k);
           nz[it] = *(const u64x2*)(zn + k);
         }
       }
