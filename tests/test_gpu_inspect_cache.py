@@ -172,3 +172,20 @@ def test_process_paths_windows_inspect_once(method, monkeypatch):
     got = api.process_paths(p)
     for lvl in range(1, 6):
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_kept_inspections_without_permutations_and_with_a_sentinel(method):
+    """iterations = 0 (no null kernel at all, App. A-3) and top_k above the path count (the sentinel, App. A-8): a replayed
+    pass returns the same lists as the inspected one and as the oracle."""
+    p = make_problem(12, 20, 9, 9, 0, 3, method=method, top_k=400, seed=51)
+    want = oracle.process_paths(p, order="canonical")
+    plan = api.ResidentPlan(p)
+    try:
+        for rep in range(3):
+            got = plan.run(keep_inspections=True)
+            check(got, want, 3)
+            assert plan.last_profile["inspect_replays"] == (0 if rep == 0 else len(plan.names))
+            assert all(len(got[name].null) == 0 for name, _ in LEVELS[:3])
+    finally:
+        plan.close()
