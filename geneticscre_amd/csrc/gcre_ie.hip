@@ -1818,7 +1818,7 @@ hipError_t launch_range_union(const uint64_t* p1, const uint64_t* pz, const int3
 // NL = 16-byte loads per row and lane = ceil(Wp / 32) (Wp <= 32 * NL).
 // ------------------------------------------------------------------------------------------------
 template <int NL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_stats_ie2(const StatsArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3 : 2))) void k_stats_ie2(const StatsArgs a) {
   typedef u64 __attribute__((ext_vector_type(2))) u64x2;
   constexpr u32 kNoRange = 0xffffffffu;
   constexpr u32 kOverChunk = 2048;
@@ -2024,7 +2024,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {
   if (a.count == 0) return hipSuccess;
   static const bool v1 = std::getenv("GCRE_STATS_V1") != nullptr;   // the per-path form (cross-check)
-  if (method == 1 && !v1 && a.Wp <= 128) {
+  if (method == 1 && !v1 && a.Wp <= 160) {
     const i64 nb = (a.count + 63) / 64;
     const i64 blocks = (nb + 3) / 4;
     const dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), block(256);
@@ -2032,7 +2032,8 @@ hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {
     if (nl <= 1) hipLaunchKernelGGL((k_stats_ie2<1>), grid, block, 0, stream, a);
     else if (nl == 2) hipLaunchKernelGGL((k_stats_ie2<2>), grid, block, 0, stream, a);
     else if (nl == 3) hipLaunchKernelGGL((k_stats_ie2<3>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_stats_ie2<4>), grid, block, 0, stream, a);
+    else if (nl == 4) hipLaunchKernelGGL((k_stats_ie2<4>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_stats_ie2<5>), grid, block, 0, stream, a);
     return hipGetLastError();
   }
   const i64 blocks = (a.count + 15) / 16;   // 4 waves x 4 paths per block and pass
