@@ -556,6 +556,8 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
   if (planes <= 8) { GCRE_IEQ_R(EXPR, 8, 2) }                              \
   else if (planes <= 10) {                                                 \
     if (gz <= 2) { GCRE_IEQ_R(EXPR, 10, 2) } else { GCRE_IEQ_R(EXPR, 10, 3) }        \
+  } else if (planes <= 11) {                                               \
+    if (gz <= 2) { GCRE_IEQ_R(EXPR, 11, 2) } else { GCRE_IEQ_R(EXPR, 11, 3) }        \
   } else if (planes <= 12) {                                               \
     if (gz <= 2) { GCRE_IEQ_R(EXPR, 12, 2) } else { GCRE_IEQ_R(EXPR, 12, 3) }        \
   } else {                                                                 \
