@@ -992,7 +992,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
     }
   };
   // live permutations whose count lies outside [lo, hi] (bounds as scalar masks, two borrow chains)
-  auto outside = [&](const u32 (&C)[L], u32 lh) -> u32 {
+  auto outside = [&](const auto& C, u32 lh) -> u32 {   // C: at least L planes
     const u32 lo = lh & 0xffffu, hi = lh >> 16;
     u32 blo = 0u, bhi = 0u;
 #pragma unroll
@@ -1075,9 +1075,24 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
       const u32 last = npaths - 1u;
       auto at = [&](u32 t2) -> u32 { return t2 < last ? t2 : last; };
       auto issue = [&](int h, u32 t2, const u32x8 offs, u32 (&yy)[8], u32 (&ZZ)[LZ]) {
+        // A wave-load costs the memory pipe the same whatever it fetches (profiles/r02_row_gather_rate.txt), and most
+        // lists are short: one half of a gene row is empty (an empty delta list), the other overlaps the path in a patient
+        // or two.  Only the entries that are not padding are fetched, in steps of four: 0, 4 or 8 loads instead of 8.
+        const u32 info = rdlane(infov[h], t2);
+        const u32 real = (info & kLinfoLenMask) - (info >> 28);
+        if (real > 4u) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
-        if (rdlane(infov[h], t2) & 1u) {   // overlap lists only
+          for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+        } else if (real > 0u) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+#pragma unroll
+          for (int j = 4; j < 8; j++) yy[j] = 0u;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) yy[j] = 0u;
+        }
+        if (info & 1u) {   // overlap lists only
           const u32x4* src = (const u32x4*)(a.planesz + (u64)rdlane(zunit[h], t2) * 256u) + lane;
 #pragma unroll
           for (int j = 0; j < GZ; j++) {
@@ -1088,10 +1103,35 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
         }
       };
       u32 C[2][L];
+      // interval tests of a half whose list is empty: its counts are the segment's base counters, its carrier total the
+      // segment's -- the same two results for every such path of the segment
+      u32 eA[2] = {0u, 0u}, eB[2] = {0u, 0u};
+      bool eok[2] = {false, false};
+      auto write_out = [&](int h, u32 t) {
+        if constexpr (OUT) {
+          const u64 rh = ((u64)a.out_first + first + t) * 2 + h;
+          u32x4* dst = (u32x4*)(a.planes_out + (((u64)kt * (u64)a.rows_out + rh) * (u64)a.go) * 256u) + lane;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (j < a.go) {
+              u32x4 v = {0u, 0u, 0u, 0u};
+              if (4 * j < L) v = u32x4{C[h][(4 * j) % L], (4 * j + 1 < L) ? C[h][(4 * j + 1) % L] : 0u,
+                                       (4 * j + 2 < L) ? C[h][(4 * j + 2) % L] : 0u, (4 * j + 3 < L) ? C[h][(4 * j + 3) % L] : 0u};
+              dst[j * 64] = v;
+            }
+          }
+        }
+      };
       auto compute = [&](int h, u32 t, const u32 (&y)[8], const u32 (&Z)[LZ]) {
         const u32 r0 = rdlane(infov[h], t);
         const u32 len = r0 & kLinfoLenMask;
         const bool overlap = (r0 & 1u) != 0u;
+        if (!overlap && len == (r0 >> 28)) {   // an empty delta list (the gene sits in the other half): the half is paths0's
+#pragma unroll
+          for (int l = 0; l < L; l++) C[h][l] = B[h][l];
+          write_out(h, t);
+          return;
+        }
         u32 S[L];
         {
           u32 S4[4];
@@ -1135,19 +1175,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
             cy = majority(B[h][l], S[l], cy);
           }
         }
-        if constexpr (OUT) {
-          const u64 rh = ((u64)a.out_first + first + t) * 2 + h;
-          u32x4* dst = (u32x4*)(a.planes_out + (((u64)kt * (u64)a.rows_out + rh) * (u64)a.go) * 256u) + lane;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (j < a.go) {
-              u32x4 v = {0u, 0u, 0u, 0u};
-              if (4 * j < L) v = u32x4{C[h][(4 * j) % L], (4 * j + 1 < L) ? C[h][(4 * j + 1) % L] : 0u,
-                                       (4 * j + 2 < L) ? C[h][(4 * j + 2) % L] : 0u, (4 * j + 3 < L) ? C[h][(4 * j + 3) % L] : 0u};
-              dst[j * 64] = v;
-            }
-          }
-        }
+        write_out(h, t);
       };
       u32 yA[8], yB[8], ZA[LZ], ZB[LZ];
 #pragma unroll
@@ -1162,9 +1190,28 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
         oB = slots[at(t + 1u) * 2u + 1u];
         compute(1, t, yB, ZB);
         // ---- a permutation is safe when (F <= ha and G <= hb) or (F <= hb and G <= ha): ha + hb <= theta ----
-        const u32 pa = outside(C[0], rdlane(lha[0], t)), pb = outside(C[0], rdlane(lhb[0], t));
-        const u32 na = outside(C[1], rdlane(lha[1], t)), nb_ = outside(C[1], rdlane(lhb[1], t));
+        u32 pa, pb, na, nb_;
+        {
+          const u32 i0 = rdlane(infov[0], t), i1 = rdlane(infov[1], t);
+          const bool e0 = !(i0 & 1u) && (i0 & kLinfoLenMask) == (i0 >> 28), e1 = !(i1 & 1u) && (i1 & kLinfoLenMask) == (i1 >> 28);
+          if (e0) {
+            if (!eok[0]) { eA[0] = outside(B[0], rdlane(lha[0], t)); eB[0] = outside(B[0], rdlane(lhb[0], t)); eok[0] = true; }
+            pa = eA[0]; pb = eB[0];
+          } else {
+            pa = outside(C[0], rdlane(lha[0], t)); pb = outside(C[0], rdlane(lhb[0], t));
+          }
+          if (e1) {
+            if (!eok[1]) { eA[1] = outside(B[1], rdlane(lha[1], t)); eB[1] = outside(B[1], rdlane(lhb[1], t)); eok[1] = true; }
+            na = eA[1]; nb_ = eB[1];
+          } else {
+            na = outside(C[1], rdlane(lha[1], t)); nb_ = outside(C[1], rdlane(lhb[1], t));
+          }
+        }
         u32 m = (pa | nb_) & (pb | na) & valid;
+#ifdef GCRE_M2_NOLOOKUP   // timing experiment only (results are wrong): what the look-ups cost
+        if (m != 0u) n_slow += 0u;
+        m = 0u;
+#endif
         if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
         n_slow++;
         const double* dp = a.d64 + sp_diag_offset(rdlane(totv[0], t));
