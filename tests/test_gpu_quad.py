@@ -79,3 +79,25 @@ def test_quad_and_single_segment_forms_agree_on_dense_rows(top_rate, monkeypatch
         for name, lst in (("1b", "lst1"), ("2", "lst2"), ("3", "lst3"), ("4", "lst4")):
             assert_same_result(got[name], want[lst])
         assert (prof["ie_quad_launches"] > 0) == (quad == "2"), prof
+
+
+def test_eleven_counter_planes(monkeypatch):
+    """Carrier totals between 1024 and 2047 need 11 counter bits: the quad kernel has variants of its own for them
+    (configs[3] runs them at full size).  1,500 patients, genes carried by 30-42 % of them: oracle results with the quad
+    form forced on, and the level-3 rows really carry that many."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_IE_QUAD", "2")
+    monkeypatch.setenv("GCRE_IE_WARM", "64")
+    rng = np.random.default_rng(11)
+    nc, nt = 760, 740
+    p = make_problem(60, 330, nc, nt, 2100, 4, method="method1", top_k=12, seed=17)
+    dense = (rng.random(p.data1.shape) < rng.uniform(0.30, 0.42, size=(p.data1.shape[0], 1))).astype(np.int32)
+    p.data1[:] = dense
+    p.data2[:] = dense[p.levels.uids["1b"].src]
+    want = oracle.process_paths(p, order="canonical", nthreads=8)
+    most = int(np.unpackbits(want["paths3"].view(np.uint8), axis=1).sum(axis=1).max())
+    assert 1024 <= most < 2048, most
+    got, prof = run_plan(p)
+    for name, lst in (("2", "lst2"), ("3", "lst3"), ("4", "lst4")):
+        assert_same_result(got[name], want[lst])
+    assert prof["ie_quad_launches"] > 0
