@@ -423,3 +423,23 @@ def test_freed_reduced_operand_is_not_used(monkeypatch):
     assert ex.profile()["ie_hinted_joins"] == 0
     junk.free()
     ex.close()
+
+
+@pytest.mark.parametrize("patients", [(2050, 2060), (3400, 3650), (4900, 4995)])
+def test_inspector_row_widths_up_to_160_words(patients, monkeypatch):
+    """The block-staged inspector handles rows of 3, 4 and 5 register blocks (65, 111 and 155 mask words here; 4 and 5
+    run two waves per SIMD): oracle results for a kept join and the joins behind it."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    nc, nt = patients
+    p = make_problem(45, 150, nc, nt, 120, 4, method="method1", top_k=10, seed=nc, table=small_table(nc, nt, 3))
+    want = oracle.process_paths(p, order="canonical", nthreads=8)
+    check_levels(api.process_paths(p), want, range(1, 5))
+    plan = api.ResidentPlan(p)
+    try:
+        got = plan.run()
+        for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4)):
+            assert_same_result(got[name], want[f"lst{lvl}"])
+        np.testing.assert_array_equal(plan.kept["3"].to_numpy(), want["paths3"])     # the rows the inspector wrote
+        np.testing.assert_array_equal(plan.kept["2"].to_numpy(), want["paths2"])
+    finally:
+        plan.close()
