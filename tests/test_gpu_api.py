@@ -321,12 +321,15 @@ def test_gwaspa_front_end_matches_oracle_and_finds_planted_pathway(signed):
 
 @pytest.mark.parametrize("method", ["method1", "method2"])
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
-def test_process_paths_on_several_devices_from_one_process(method, devices, monkeypatch):
+@pytest.mark.parametrize("window_tiles", ["", "1"])
+def test_process_paths_on_several_devices_from_one_process(method, devices, window_tiles, monkeypatch):
     """gcre_process_paths_devices (what the .Call shim calls): one context and host thread per listed device, joined paths
     sharded, maxima and top-k tables merged on the host -- rehearsed here with the one GPU of the box listed up to three
     times.  Bit-identical to the oracle (and hence to the single-context call) for every device list.  The device threads
     also MAX-merge their running maxima during the larger joins (ExchangeHub; GCRE_EXCHANGE_UNIT makes these joins large)."""
     monkeypatch.setenv("GCRE_EXCHANGE_UNIT", "50")
+    if window_tiles:   # two permutation windows (2048 + 252): every device replays its inspections in the second one
+        monkeypatch.setenv("GCRE_WINDOW_TILES", window_tiles)
     p = make_problem(70, 260, 33, 41, 2300, 5, method=method, top_k=11, seed=21, table=small_table(33, 41, 5))
     want = oracle.process_paths(p, order="canonical", nthreads=4)
     got = api.process_paths_devices(p, devices)
