@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 namespace gcre {
@@ -248,30 +249,48 @@ int gcre_values_table(int n_cases, int n_ctrls, double* out) {
   if (n_cases < 0 || n_ctrls < 0 || !out) return GCRE_ERR_ARG;
   const int n = n_cases + n_ctrls;
   const size_t cols = (size_t)n_ctrls + 1;
-  auto lchoose = [](double a, double b) { return std::lgamma(a + 1.0) - std::lgamma(b + 1.0) - std::lgamma(a - b + 1.0); };
-  std::vector<double> prob, sorted, csum;
-  double max_finite = -std::numeric_limits<double>::infinity();
-  for (int i = 0; i <= n; i++) {
-    const int lo = std::max(0, i - n_ctrls), hi = std::min(i, n_cases);
-    const size_t m = (size_t)(hi - lo + 1);
-    prob.resize(m);
-    const double denom = lchoose(n, i);
-    for (size_t k = 0; k < m; k++) {
-      const int x = lo + (int)k;
-      prob[k] = std::exp(lchoose(n_cases, x) + lchoose(n_ctrls, i - x) - denom);   // dhyper(x, nCases, nControls, i)
+  // lgamma(k + 1) once per k (three calls per cell otherwise: the same values, the table took a minute at 10,000
+  // patients); the diagonals are independent and are dealt round the host threads
+  std::vector<double> lg((size_t)n + 2);
+  for (int k = 0; k <= n + 1; k++) lg[(size_t)k] = std::lgamma((double)k + 1.0);
+  auto lchoose = [&](int a, int b) { return lg[(size_t)a] - lg[(size_t)b] - lg[(size_t)(a - b)]; };
+  int T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (n < 512) T = 1;
+  std::vector<double> tmax((size_t)T, -std::numeric_limits<double>::infinity());
+  auto work = [&](int t) {
+    std::vector<double> prob, sorted, csum;
+    double max_finite = -std::numeric_limits<double>::infinity();
+    for (int i = t; i <= n; i += T) {
+      const int lo = std::max(0, i - n_ctrls), hi = std::min(i, n_cases);
+      const size_t m = (size_t)(hi - lo + 1);
+      prob.resize(m);
+      const double denom = lchoose(n, i);
+      for (size_t k = 0; k < m; k++) {
+        const int x = lo + (int)k;
+        prob[k] = std::exp(lchoose(n_cases, x) + lchoose(n_ctrls, i - x) - denom);   // dhyper(x, nCases, nControls, i)
+      }
+      sorted = prob;
+      std::stable_sort(sorted.begin(), sorted.end());
+      csum.resize(m);
+      double run = 0;
+      for (size_t k = 0; k < m; k++) { run += sorted[k]; csum[k] = run; }
+      for (size_t k = 0; k < m; k++) {
+        const size_t upto = (size_t)(std::upper_bound(sorted.begin(), sorted.end(), prob[k] * (1.0 + 1e-12)) - sorted.begin());
+        const double v = -std::log(csum[upto - 1]);
+        out[(size_t)(lo + (int)k) * cols + (size_t)(i - lo - (int)k)] = v;
+        if (std::isfinite(v)) max_finite = std::max(max_finite, v);
+      }
     }
-    sorted = prob;
-    std::stable_sort(sorted.begin(), sorted.end());
-    csum.resize(m);
-    double run = 0;
-    for (size_t k = 0; k < m; k++) { run += sorted[k]; csum[k] = run; }
-    for (size_t k = 0; k < m; k++) {
-      const size_t upto = (size_t)(std::upper_bound(sorted.begin(), sorted.end(), prob[k] * (1.0 + 1e-12)) - sorted.begin());
-      const double v = -std::log(csum[upto - 1]);
-      out[(size_t)(lo + (int)k) * cols + (size_t)(i - lo - (int)k)] = v;
-      if (std::isfinite(v)) max_finite = std::max(max_finite, v);
-    }
+    tmax[(size_t)t] = max_finite;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
   }
+  double max_finite = -std::numeric_limits<double>::infinity();
+  for (double v : tmax) max_finite = std::max(max_finite, v);
   for (size_t k = 0; k < ((size_t)n_cases + 1) * cols; k++)
     if (!std::isfinite(out[k])) out[k] = max_finite + 1.0;
   return GCRE_OK;
