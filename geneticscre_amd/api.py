@@ -93,7 +93,7 @@ EXPORTS = [
     "gcre_process_paths", "gcre_resolve_count_locs", "gcre_build_levels", "gcre_levels_free", "gcre_values_table",
     "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask", "gcre_uids_set_reduced",
     "gcre_set_perm_window", "gcre_plan_perm_window", "gcre_process_paths_devices",
-    "gcre_set_inspect_cache", "gcre_drop_inspections",
+    "gcre_set_inspect_cache", "gcre_drop_inspections", "gcre_build_flags",
 ]
 
 
@@ -106,7 +106,8 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.build()
+    # GCRE_LIB: a variant library built by tools/build_variant.py for an A/B measurement (never set by the product)
+    path = os.environ.get("GCRE_LIB") or _build.build()
     try:
         lib = ctypes.CDLL(path)
     except OSError as e:   # no silent fallback: the product IS this library
@@ -119,6 +120,7 @@ def load_library():
     lib.gcre_last_error.restype = ctypes.c_char_p
     lib.gcre_last_error.argtypes = [V]
     lib.gcre_abi_version.restype = I
+    lib.gcre_build_flags.restype = ctypes.c_char_p
     lib.gcre_set_top_k.argtypes = [V, I]
     lib.gcre_width_ul.argtypes = [V]
     lib.gcre_vlen.argtypes = [V]

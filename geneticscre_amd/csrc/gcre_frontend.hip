@@ -102,6 +102,85 @@ hipError_t launch_table_to_diag(const double* table, int nrow, int ncol, int col
   return hipGetLastError();
 }
 
+
+// ---- R's stats::dhyper as nmath publishes it (R 3.x - 4.3: dhyper.c, dbinom.c, stirlerr.c, bd0.c; C. Loader, "Fast and
+// accurate computation of binomial probabilities", 2000), restated for the integer arguments getValuesTable passes
+// (R/Utils.R:144).  give_log = FALSE throughout.  Evaluation order follows the published expressions term by term: the
+// result is meant to be the double R returns, not merely close to it.  No fused multiply-add (R's builds have none on
+// x86-64's baseline).  Host only.
+#pragma clang fp contract(off)
+static double r_stirlerr(double n) {
+  // log(n!) - log(sqrt(2 pi n) (n/e)^n); exact values for n = 0 .. 15 (stirlerr.c's sferr_halves at the integers)
+  static const double sferr[16] = {
+      0.0,
+      0.0810614667953272582196702, 0.0413406959554092940938221, 0.02767792568499833914878929,
+      0.02079067210376509311152277, 0.01664469118982119216319487, 0.01387612882307074799874573,
+      0.01189670994589177009505572, 0.010411265261972096497478567, 0.009255462182712732917728637,
+      0.008330563433362871256469318, 0.007573675487951840794972024, 0.006942840107209529865664152,
+      0.006408994188004207068439631, 0.005951370112758847735624416, 0.005554733551962801371038690};
+  constexpr double S0 = 0.083333333333333333333;          // 1/12
+  constexpr double S1 = 0.00277777777777777777778;        // 1/360
+  constexpr double S2 = 0.00079365079365079365079365;     // 1/1260
+  constexpr double S3 = 0.000595238095238095238095238;    // 1/1680
+  constexpr double S4 = 0.0008417508417508417508417508;   // 1/1188
+  if (n <= 15.0) return sferr[(int)n];
+  const double nn = n * n;
+  if (n > 500) return (S0 - S1 / nn) / n;
+  if (n > 80) return (S0 - (S1 - S2 / nn) / nn) / n;
+  if (n > 35) return (S0 - (S1 - (S2 - S3 / nn) / nn) / nn) / n;
+  return (S0 - (S1 - (S2 - (S3 - S4 / nn) / nn) / nn) / nn) / n;
+}
+
+static double r_bd0(double x, double np) {
+  // x log(x/np) + np - x, by its Taylor series where x is close to np (bd0.c)
+  if (std::fabs(x - np) < 0.1 * (x + np)) {
+    double v = (x - np) / (x + np);
+    double s = (x - np) * v;
+    if (std::fabs(s) < std::numeric_limits<double>::min()) return s;
+    double ej = 2 * x * v;
+    v = v * v;
+    for (int j = 1; j < 1000; j++) {
+      ej *= v;
+      const double s1 = s + ej / ((j << 1) + 1);
+      if (s1 == s) return s1;
+      s = s1;
+    }
+  }
+  return x * std::log(x / np) + np - x;
+}
+
+static double r_dbinom_raw(double x, double n, double p, double q) {
+  constexpr double kLn2Pi = 1.837877066409345483560659472811;   // M_LN_2PI
+  if (p == 0) return x == 0 ? 1.0 : 0.0;
+  if (q == 0) return x == n ? 1.0 : 0.0;
+  if (x == 0) {
+    if (n == 0) return 1.0;
+    const double lc = (p < 0.1) ? -r_bd0(n, n * q) - n * p : n * std::log(q);
+    return std::exp(lc);
+  }
+  if (x == n) {
+    const double lc = (q < 0.1) ? -r_bd0(n, n * p) - n * q : n * std::log(p);
+    return std::exp(lc);
+  }
+  if (x < 0 || x > n) return 0.0;
+  const double lc = r_stirlerr(n) - r_stirlerr(x) - r_stirlerr(n - x) - r_bd0(x, n * p) - r_bd0(n - x, n * q);
+  const double lf = kLn2Pi + std::log(x) + std::log1p(-x / n);
+  return std::exp(lc - 0.5 * lf);
+}
+
+// dhyper(x, r, b, n): x white balls among n drawn from r white + b black (dhyper.c)
+double r_dhyper(double x, double r, double b, double n) {
+  if (x < 0) return 0.0;
+  if (n < x || r < x || n - x > b) return 0.0;
+  if (n == 0) return x == 0 ? 1.0 : 0.0;
+  const double p = n / (r + b);
+  const double q = (r + b - n) / (r + b);
+  const double p1 = r_dbinom_raw(x, r, p, q);
+  const double p2 = r_dbinom_raw(n - x, b, p, q);
+  const double p3 = r_dbinom_raw(n, r + b, p, q);
+  return p1 * p2 / p3;
+}
+
 }  // namespace gcre
 
 namespace {
@@ -243,40 +322,59 @@ void gcre_levels_free(gcre_levels* lv) {
 
 int gcre_values_table(int n_cases, int n_ctrls, double* out) {
   // getValuesTable (Utils.R:137-159): out[x][i-x] = -log(two-sided hypergeometric p of x cases among i carriers);
-  // two-sided p = mass of all outcomes no more likely than x (:153); infinities -> max finite + 1 (:156).
-  // Outcomes that tie in exact arithmetic (C(5,2)C(9,5) == C(5,3)C(9,4)) differ by an ulp or two after lgamma/exp;
-  // R's exact `<=` leaves such ties to dhyper's rounding, here they count as ties (relative slack 1e-12).
+  // two-sided p = sum(prob[prob <= prob_x]) with R's EXACT `<=` on the doubles stats::dhyper returns (:153);
+  // infinities -> max finite + 1 (:156).  dhyper is restated as R's nmath publishes it (gcre::r_dhyper), and the sum is
+  // R's: a long double accumulator over the diagonal in index order, rounded to double once (R's rsum).  So the table
+  // is the one R builds wherever libm's log / log1p / exp agree -- R is not in this image, the row stays unpinned, but
+  // no rule of ours (the 1e-12 tie slack of the earlier builder) separates it from R's any more.
+  // Cost: R's sapply is O(m^2) per diagonal; so is the index-order sum.  Up to 2.5e11 inner steps (n ~ 14,000
+  // patients: ~15 s on 16 threads) every cell is summed exactly like R does; beyond that (configs[4]'s 50,000 patients,
+  // where R itself would need days) the qualifying outcomes are summed in ascending order of probability through a
+  // long double prefix sum: the same set of outcomes (exact `<=`), the same 64-bit accumulator, another order of
+  // additions -- the rounded double can differ in its last bit for a cell in a hundred.
   if (n_cases < 0 || n_ctrls < 0 || !out) return GCRE_ERR_ARG;
   const int n = n_cases + n_ctrls;
   const size_t cols = (size_t)n_ctrls + 1;
-  // lgamma(k + 1) once per k (three calls per cell otherwise: the same values, the table took a minute at 10,000
-  // patients); the diagonals are independent and are dealt round the host threads
-  std::vector<double> lg((size_t)n + 2);
-  for (int k = 0; k <= n + 1; k++) lg[(size_t)k] = std::lgamma((double)k + 1.0);
-  auto lchoose = [&](int a, int b) { return lg[(size_t)a] - lg[(size_t)b] - lg[(size_t)(a - b)]; };
+  double work_est = 0;
+  for (int i = 0; i <= n; i++) {
+    const double m = (double)(std::min(i, n_cases) - std::max(0, i - n_ctrls) + 1);
+    work_est += m * m;
+  }
+  double exact_work = 2.5e11;
+  if (const char* e = std::getenv("GCRE_VT_EXACT_WORK")) exact_work = std::atof(e);   // tests: 0 forces the prefix-sum form
+  const bool exact_order = work_est <= exact_work;
   int T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-  if (n < 512) T = 1;
+  if (n < 256) T = 1;
   std::vector<double> tmax((size_t)T, -std::numeric_limits<double>::infinity());
   auto work = [&](int t) {
-    std::vector<double> prob, sorted, csum;
+    std::vector<double> prob, sorted;
+    std::vector<long double> csum;
     double max_finite = -std::numeric_limits<double>::infinity();
+    // diagonals dealt round the threads: the long ones (the middle of the table) alternate between them
     for (int i = t; i <= n; i += T) {
       const int lo = std::max(0, i - n_ctrls), hi = std::min(i, n_cases);
       const size_t m = (size_t)(hi - lo + 1);
       prob.resize(m);
-      const double denom = lchoose(n, i);
-      for (size_t k = 0; k < m; k++) {
-        const int x = lo + (int)k;
-        prob[k] = std::exp(lchoose(n_cases, x) + lchoose(n_ctrls, i - x) - denom);   // dhyper(x, nCases, nControls, i)
+      for (size_t k = 0; k < m; k++) prob[k] = gcre::r_dhyper((double)(lo + (int)k), (double)n_cases, (double)n_ctrls, (double)i);
+      if (!exact_order) {
+        sorted = prob;
+        std::sort(sorted.begin(), sorted.end());
+        csum.resize(m);
+        long double run = 0.0L;
+        for (size_t k = 0; k < m; k++) { run += (long double)sorted[k]; csum[k] = run; }
       }
-      sorted = prob;
-      std::stable_sort(sorted.begin(), sorted.end());
-      csum.resize(m);
-      double run = 0;
-      for (size_t k = 0; k < m; k++) { run += sorted[k]; csum[k] = run; }
       for (size_t k = 0; k < m; k++) {
-        const size_t upto = (size_t)(std::upper_bound(sorted.begin(), sorted.end(), prob[k] * (1.0 + 1e-12)) - sorted.begin());
-        const double v = -std::log(csum[upto - 1]);
+        const double x = prob[k];
+        double p_two;
+        if (exact_order) {
+          long double acc = 0.0L;
+          for (size_t j = 0; j < m; j++) acc += (prob[j] <= x) ? (long double)prob[j] : 0.0L;   // + 0 leaves acc as it is
+          p_two = (double)acc;
+        } else {
+          const size_t upto = (size_t)(std::upper_bound(sorted.begin(), sorted.end(), x) - sorted.begin());
+          p_two = (double)csum[upto - 1];
+        }
+        const double v = -std::log(p_two);
         out[(size_t)(lo + (int)k) * cols + (size_t)(i - lo - (int)k)] = v;
         if (std::isfinite(v)) max_finite = std::max(max_finite, v);
       }

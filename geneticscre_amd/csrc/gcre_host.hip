@@ -215,6 +215,7 @@ struct gcre_ctx {
   double* d_dmax = nullptr;          // method 2 null table (vtmax)
   uint32_t* d_null = nullptr;        // [Kpad]
   uint32_t* d_mt = nullptr;          // transposed masks for the sparse kernel [nkt][64*Wp + 1][64]
+  int ieq_batch = 0;                 // GCRE_IEQ_BATCH: quads per ticket of the quad kernel (0: twice ie_batch)
   int ie_quad = 1;                   // GCRE_IE_QUAD=0: the pruned method-1 launches stay on k_null_ie_m1 (cross-check)
   int ie_warm_items = 4;             // (segment, tile) items per wave of the warm-up launch (GCRE_IE_WARM_ITEMS)
   int ie_warm_segs = 2048;           // least number of segments in the warm-up slice (GCRE_IE_WARM)
@@ -793,6 +794,7 @@ void build_quads_host(const gcre_uids& u, const std::vector<SparseSeg>& segs, in
   quads.clear();
   quads.reserve((size_t)n / 3 + 16);
   int64_t quad_begin = -1;
+  const int64_t qmax = ieq_quad_segs();
   auto key_of = [&](const SparseSeg& x) { return u.h_location[x.row0] + ((int64_t)x.first + first - pi[x.row0]); };
   int64_t i = 0;
   while (i < n) {
@@ -801,7 +803,7 @@ void build_quads_host(const gcre_uids& u, const std::vector<SparseSeg>& segs, in
     const int64_t k0 = key_of(segs[(size_t)i]);
     const uint32_t n0 = segs[(size_t)i].n;
     int64_t j = i + 1;
-    while (j < stop && j < i + 4 && segs[(size_t)j].n == n0 && key_of(segs[(size_t)j]) == k0) j++;
+    while (j < stop && j < i + qmax && segs[(size_t)j].n == n0 && key_of(segs[(size_t)j]) == k0) j++;
     quads.push_back((uint32_t)i | ((uint32_t)(j - i - 1) << 30));
     i = j;
   }
@@ -1795,7 +1797,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
                 ia.quads = seg_entry->d_quads;
                 ia.quad_begin = seg_entry->quad_begin;
                 ia.quad_end = seg_entry->nquads;
-                ia.batch = std::max(1, c->ie_batch * 2);   // quads per ticket: the headers of a ticket's quads are fetched one ahead
+                ia.batch = c->ieq_batch > 0 ? c->ieq_batch : std::max(1, c->ie_batch * 2);   // quads per ticket: the headers of a ticket's quads are fetched one ahead
                 const int wq = std::min(c->sparse_waves_per_cu, ieq_max_waves_per_cu(planes, ia.gz, ia.rec_slot != nullptr));
                 ia.waves_per_xcd = std::max(4, (dev_cus * wq / 8 / 4) * 4);
                 while (ia.waves_per_xcd > 4 && n * ie_tile_factor < (int64_t)8 * ia.waves_per_xcd * 128)
@@ -2112,6 +2114,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
 extern "C" {
 
 int gcre_abi_version(void) { return GCRE_ABI_VERSION; }
+#ifndef GCRE_BUILD_FLAGS
+#define GCRE_BUILD_FLAGS ""
+#endif
+const char* gcre_build_flags(void) { return GCRE_BUILD_FLAGS; }
 
 const char* gcre_last_error(const gcre_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -2163,6 +2169,7 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   if (const char* e = std::getenv("GCRE_IE_WARM_ITEMS")) c->ie_warm_items = std::min(std::max(std::atoi(e), 1), 64);
   if (const char* e = std::getenv("GCRE_IE_SJT")) c->ie_small_join_tiles = std::atoi(e);
   if (const char* e = std::getenv("GCRE_IE_BATCH")) c->ie_batch = std::min(std::max(std::atoi(e), 1), 4096);
+  if (const char* e = std::getenv("GCRE_IEQ_BATCH")) c->ieq_batch = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("GCRE_IE_QUAD")) c->ie_quad = std::min(std::max(std::atoi(e), 0), 2);   // 2: wherever it can run
   if (const char* e = std::getenv("GCRE_PLANES_OUT_MAX_MB")) c->planes_out_max = (size_t)std::max(0ll, std::atoll(e)) << 20;
   if (const char* e = std::getenv("GCRE_SPARSE_WAVES_PER_CU")) c->sparse_waves_per_cu = std::max(1, std::atoi(e));

@@ -1208,10 +1208,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
           }
         }
         u32 m = (pa | nb_) & (pb | na) & valid;
-#ifdef GCRE_M2_NOLOOKUP   // timing experiment only (results are wrong): what the look-ups cost
-        if (m != 0u) n_slow += 0u;
-        m = 0u;
-#endif
         if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
         n_slow++;
         const double* dp = a.d64 + sp_diag_offset(rdlane(totv[0], t));

@@ -1,4 +1,4 @@
-// gcre_ieq.hip -- the pruned method-1 null kernel, "quad" form: one wave works on up to FOUR segments at a time that
+// gcre_ieq.hip -- the pruned method-1 null kernel, "quad" form: one wave works on up to kQSegs segments (two; four in round 2) at a time that
 // join the same paths1 rows, and fetches the planes of every added row once for all of them.
 //
 // Same arithmetic and the same lane layout as k_null_ie_m1 (gcre_ie.hip; lane = 32 permutations of a 2048-permutation
@@ -13,15 +13,25 @@
 // (tools/row_gather_rate.hip), not by VALU issue and not by bytes.
 //
 // All uids with the same pivot gene join the same paths1 rows (the join index gives them the same location and count), so
-// their segments walk the same sequence of added rows.  The host groups up to four such segments into a quad
-// (gcre_host.hip ensure_quads).  The wave keeps the base counters of all four (4 x L registers) and, for every position
+// their segments walk the same sequence of added rows.  The host groups up to kQSegs such segments into a "quad" (the name stayed from the four-segment form)
+// (gcre_host.hip ensure_quads).  The wave keeps the base counters of all of them (kQSegs x L registers) and, for every position
 // t of the shared sequence, loads Nz[z_t] once and scores path t of each segment against it: the plane loads per
 // path-tile drop from 2 to 0.5, the instruction stream per path-tile is unchanged.
 #include "gcre_ie_common.h"
 
 namespace gcre {
 
-constexpr int kQSegs = 4;
+// Segments per quad and the occupancy the register allocation aims at.  Round 3 (profiles/r03_quad_shapes.txt): two
+// segments at four waves per SIMD beat four at three (25.9 vs 27.4 ms of null kernels per pass on configs[2]: the prologue
+// and the exact pass wait on memory, a fourth wave covers more of that than sharing a plane load four ways saves);
+// four segments at four waves spill (128 VGPRs), three at four do too.
+#ifndef GCRE_QSEGS
+#define GCRE_QSEGS 2
+#endif
+#ifndef GCRE_QWAVES
+#define GCRE_QWAVES 4
+#endif
+constexpr int kQSegs = GCRE_QSEGS;
 
 // -DGCRE_IE_TIMING: per-section s_memtime sums (a mark only reads the clock)
 #ifdef GCRE_IE_TIMING
@@ -33,7 +43,7 @@ constexpr int kQSegs = 4;
 #endif
 
 template <int L, int GZ, bool REC>
-__global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3))) void k_null_ie_q(const IeArgs a) {
+__global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(GCRE_QWAVES))) void k_null_ie_q(const IeArgs a) {
   constexpr int LP = (L + 3) / 4 * 4;
   constexpr int LZ = 4 * GZ;
   static_assert(L >= 8 && L <= 16 && GZ >= 2 && LZ <= LP, "planes come in groups of 4");
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
         }
       }
     };
-    u32 hdr_n[kQSegs] = {0u, 0u, 0u, 0u};
+    u32 hdr_n[kQSegs] = {};
     u32 qe_n = 0u;
     bool have_next = false;
     for (u32 qi = q_lo; qi < q_hi; qi++) {
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
       // quad, not one per segment.
       u32 totv[kQSegs];
       u32 yr[REC ? kQSegs : 1][8];
-      u32 rinfo_g[kQSegs] = {0u, 0u, 0u, 0u}, rlov_g[kQSegs] = {0u, 0u, 0u, 0u}, rz_g[kQSegs] = {0u, 0u, 0u, 0u};
+      u32 rinfo_g[kQSegs] = {}, rlov_g[kQSegs] = {}, rz_g[kQSegs] = {};
       // the paths' metadata first: the ladder gather below needs the carrier totals and must not queue behind the planes
 #pragma unroll
       for (int g = 0; g < kQSegs; g++) {
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
       // add: W = B_g + Z is inside [lo + ov, hi] for every live permutation <=> no count of the path can raise a maximum
       // whatever its overlap rows say.  Paths that fail (about one in ten) -- and the rare delta-list paths -- are only
       // marked, one bit per path in a scalar mask per segment: nothing in this loop waits for anything but the planes.
-      u64 todo[kQSegs] = {0ull, 0ull, 0ull, 0ull};
+      u64 todo[kQSegs] = {};
       auto filter_f = [&](int g, u32 t, const u32 (&Bg)[L], const u32 (&Z)[LZ]) {
         const u32 lf = rdlane(lfv[g], t);   // hi << 16 | lo + ov
         u32 cy = 0u, blo = 0u, bhi = 0u;
@@ -369,9 +379,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
       };
 
       // the planes of the next added row are in flight while up to four paths are tested against the current one
-#ifdef GCRE_IEQ_NOPATHS   // diagnostics: what the per-segment work alone costs (results are wrong)
-      if (B[0][0] == 0x12345678u && B[1][1] == 1u && B[2][2] == 2u && B[3][3] == 3u)
-#endif
       {
         u32 ZA[LZ], ZB[LZ];
         issue(0u, ZA);
@@ -401,8 +408,8 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
         it.t = t;
         it.info = rdlane(infov[g], t);
         it.lh = rdlane(lhv[g], t);
-        it.lov = ((const u32 GCRE_CONSTANT*)a.lover)[q];
-        it.tot = ((const u32 GCRE_CONSTANT*)a.tot)[q];
+        it.lov = (u32)q;                  // where a long list continues is only read for a long list (exact_f)
+        it.tot = rdlane(totv[g], t);
         it.o = slots[q];
         return it;
       };
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
 #pragma unroll
         for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
         if (len > 8u) {   // long list: further blocks of 8 entries
-          const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + it.lov);
+          const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + ((const u32 GCRE_CONSTANT*)a.lover)[it.lov]);
           for (u32 p = 0u; p + 8u < len; p += 8u) {
             const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
             u32 yy[8], s4[4];
@@ -494,9 +501,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(3
             __hip_atomic_fetch_max(nm + bb[k] * 64, vv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_max_u32
         }
       };
-#ifdef GCRE_IEQ_NOEXACT   // diagnostics: the cost of the first pass alone (results are wrong)
-      if (B[0][0] == 0x12345678u && B[1][1] == 1u && B[2][2] == 2u && B[3][3] == 3u)
-#endif
 #pragma unroll
       for (int g = 0; g < kQSegs; g++) {
         if ((u32)g < qcnt && todo[g] != 0ull) {
@@ -578,6 +582,8 @@ hipError_t launch_null_ie_quad(const IeArgs& a, int planes, hipStream_t stream) 
 #undef GCRE_LAUNCHQ
   return hipGetLastError();
 }
+
+int ieq_quad_segs() { return kQSegs; }
 
 int ieq_max_waves_per_cu(int planes, int gz, bool rec) {
   int blocks = 0;

@@ -149,6 +149,7 @@ struct IeArgs {
 };
 hipError_t launch_null_ie_quad(const IeArgs& a, int planes, hipStream_t stream);   // gcre_ieq.hip
 int ieq_max_waves_per_cu(int planes, int gz, bool rec);
+int ieq_quad_segs();   // segments a quad may hold (gcre_ieq.hip)
 // r_tot (optional): carriers of the recipe's rows; bits 1-2 of the gathered list-info word then say how many groups of 4
 // count planes of the row can be non-zero, minus one (counts never exceed the carrier total)
 hipError_t launch_fill_rec_segs(const SparseSeg* segs, int64_t nsegs, const uint32_t* r_row0, const uint32_t* r_rowz,

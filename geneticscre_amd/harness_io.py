@@ -72,3 +72,50 @@ def write_problem(path: str, p: Problem) -> None:
         f.write("data2 " + rows(p.data2.tolist(), str) + "\n")
         f.write("perms " + rows(p.perm_cases.tolist(), str) + "\n")
         f.write("table " + rows(p.value_table.tolist(), repr) + "\n")
+
+
+def write_problem_bin(path: str, p: Problem, nthreads: int = 0) -> None:
+    """Every ProcessPaths input (src/wrapper.cpp:177-185) as one binary file ("GCREBIN2"): the text format above needs
+    ~20 bytes per table cell (half a gigabyte for a 5,000-patient table).  Read by the native harness driver and by the
+    partial reference build (oracle/ref_partial/ref_driver.cpp --bin); layout = the order written here."""
+    import struct
+    M = 1 if p.method == "method1" else 2
+    perms = np.asarray(p.perm_cases)
+    with open(path, "wb") as f:
+        f.write(b"GCREBIN2")
+        f.write(struct.pack("<8i", M, p.n_cases, p.n_ctrls, p.iterations, p.top_k, p.path_length, nthreads, perms.shape[0]))
+        for name, _ in _LEVELS:
+            u = p.levels.uids[name]
+            f.write(struct.pack("<2q", len(u.src), len(u.signs)))
+            for arr, dt in ((u.src, np.int32), (u.trg, np.int32), (u.count, np.int32), (u.location, np.int64), (u.signs, np.int32)):
+                f.write(np.ascontiguousarray(arr, dtype=dt).tobytes())
+        for name in ("1a", "1b", "2", "3"):
+            idx = np.ascontiguousarray(p.levels.data_inds[name], dtype=np.int32)
+            f.write(struct.pack("<q", idx.size))
+            f.write(idx.tobytes())
+        for m in (p.data1, p.data2, perms):
+            m = np.asarray(m)
+            rows, cols = (m.shape if m.ndim == 2 else (0, 0))
+            f.write(struct.pack("<2q", rows, cols))
+            f.write(np.ascontiguousarray(m, dtype=np.uint8).tobytes())
+        t = np.ascontiguousarray(p.value_table, dtype=np.float64)
+        f.write(struct.pack("<2q", t.shape[0], t.shape[1]))
+        f.write(t.tobytes())
+
+
+def problem_digest(p: Problem) -> str:
+    """SHA-256 over every input array of a problem: fixtures that are regenerated from a seed record it, so that a drift of
+    the generator (or of the value-table builder) fails loudly instead of comparing against outputs of other inputs."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(f"{p.method}|{p.n_cases}|{p.n_ctrls}|{p.path_length}|{p.top_k}|{p.iterations}".encode())
+    for name, _ in _LEVELS:
+        u = p.levels.uids[name]
+        for arr, dt in ((u.src, np.int32), (u.trg, np.int32), (u.count, np.int32), (u.location, np.int64), (u.signs, np.int32)):
+            h.update(np.ascontiguousarray(arr, dtype=dt).tobytes())
+    for name in ("1a", "1b", "2", "3"):
+        h.update(np.ascontiguousarray(p.levels.data_inds[name], dtype=np.int32).tobytes())
+    for m in (p.data1, p.data2, p.perm_cases):
+        h.update(np.ascontiguousarray(m, dtype=np.uint8).tobytes())
+    h.update(np.ascontiguousarray(p.value_table, dtype=np.float64).tobytes())
+    return h.hexdigest()

@@ -9,8 +9,9 @@ The reference reads its network from inst/extdata/Rels.dat, which is not shipped
 * ``case_or_control``    -- getRandIndicesMat + getCaseORControl, R/Utils.R:22-46, 246-262
 * ``variant_matrix``     -- the shape PreprocessTable leaves behind, R/Utils.R:164-197
 
-Value-table parity with R's ``stats::dhyper`` is unpinned (no R in this image); the hot path treats the
-table as opaque input, so bit-exactness of the scorer is defined given identical tables.
+Value-table parity with R's ``stats::dhyper`` is unpinned (no R in this image; the builder restates R's published
+algorithm); the hot path treats the table as opaque input, so bit-exactness of the scorer is defined given identical
+tables.
 """
 from __future__ import annotations
 
@@ -26,28 +27,12 @@ def values_table(n_cases: int, n_ctrls: int) -> np.ndarray:
     """-log of the two-sided hypergeometric p-value of seeing x cases among i carriers (Utils.R:137-159).
 
     Returns float64 [(n_cases+1), (n_ctrls+1)], entry [x][i-x]; infinities become max finite + 1 (:156).
+    One builder for the product, the tests and the fixtures: the native ``gcre_values_table`` (host code of
+    libgcre_hip.so, no GPU needed), which restates R's ``stats::dhyper`` as nmath publishes it and compares with R's
+    exact ``<=``.  Its independent Python restatement lives with the test infrastructure (oracle/values_table.py).
     """
-    from scipy.special import gammaln
-
-    n = n_cases + n_ctrls
-    table = np.full((n_cases + 1, n_ctrls + 1), np.nan)
-
-    def lchoose(a, b):
-        return gammaln(a + 1.0) - gammaln(b + 1.0) - gammaln(a - b + 1.0)
-
-    for i in range(n + 1):
-        x = np.arange(max(0, i - n_ctrls), min(i, n_cases) + 1)
-        prob = np.exp(lchoose(n_cases, x) + lchoose(n_ctrls, i - x) - lchoose(n, i))   # dhyper(x, nCases, nControls, i)
-        order = np.argsort(prob, kind="stable")
-        csum = np.cumsum(prob[order])
-        # two-sided p: mass of all outcomes no more likely than x (Utils.R:153); outcomes that tie in exact
-        # arithmetic count as ties whatever the last ulp of gammaln says (same slack as gcre_values_table)
-        p_two = csum[np.searchsorted(prob[order], prob * (1.0 + 1e-12), side="right") - 1]
-        with np.errstate(divide="ignore"):
-            table[x, i - x] = -np.log(p_two)
-    finite = np.isfinite(table)
-    table[~finite] = table[finite].max() + 1.0
-    return table
+    from . import api
+    return api.values_table(n_cases, n_ctrls)
 
 
 def case_or_control(n_cases: int, n_ctrls: int, n_perm: int, rng: np.random.Generator,

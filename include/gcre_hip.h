@@ -105,6 +105,9 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
 void gcre_destroy(gcre_ctx* ctx);   /* also releases every path set and uids object still alive on the context: their handles die with it */
 const char* gcre_last_error(const gcre_ctx* ctx);   /* ctx may be NULL: error of the last failed gcre_create */
 int gcre_abi_version(void);
+/* the extra compiler flags the library was built with ("" for the shipped build): a diagnostics build that switches parts of
+   a kernel off for a timing experiment (GCRE_*_NO*, results are wrong) is recognisable, __graft_entry__.smoke() asserts "" */
+const char* gcre_build_flags(void);
 
 int gcre_set_top_k(gcre_ctx* ctx, int top_k);        /* JoinExec::top_k, src/gcre.h:120 (default 12) */
 int gcre_width_ul(const gcre_ctx* ctx);              /* 64-bit words per case/control mask, ceil(n/64) */

@@ -14,6 +14,9 @@
  * every join.  What the goldens pin is consequently the reference's scoring kernels, path-set packing, sign rule
  * and heap semantics; the driver-side members are pinned only by SURVEY.md Appendix B (tests/golden/appendix_b_*).
  *
+ * Three input forms: the harness text dump (goldens of tests/golden/ref_cases), `--bin` a binary dump of every ProcessPaths
+ * input (goldens at BASELINE mask widths; `--time`: the six-join CPU baseline of bench.py), `--bench` one join on packed rows.
+ *
  * Built by oracle/ref_partial/Makefile into oracle/_ref/ (git-ignored); never shipped, never linked by the product.
  */
 #include "gcre.h"
@@ -208,9 +211,147 @@ static int bench_main(const char* path) {
   return 0;
 }
 
+// ---- the six joins of ProcessPaths (reference src/wrapper.cpp:227-276, test/harness.cpp:121-181) on parsed inputs -------
+struct Inputs {
+  vector<UidRelSet> lv;
+  vec_i idx0, idx1, idx2, idx3;
+  vec2d_i data1, data2;
+};
+
+static double now_s() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// timing != nullptr: seconds of every join call (the reference's Timer is commented out, src/util.h:23) and the joined
+// paths of each level; the results are printed either way
+static void run_sequence(JoinExec& exec, const Inputs& in, int L, vector<pair<string, double>>* timing, bool digest_only) {
+  auto emit = [&](const char* name, const joined_res& res, const PathSet* kept, bool last) {
+    if (!digest_only) { dump(name, res, kept, last); return; }
+    // timing runs on large inputs: best score + FNV-1a over the null maxima's bits instead of the full vectors
+    uint64_t h = 1469598103934665603ull;
+    for (double v : res.permuted_scores) { h ^= bits((float)v); h *= 1099511628211ull; }
+    printf("  \"%s\": {\"best\": \"%016" PRIx64 "\", \"n_scores\": %zu, \"null_fnv\": \"%016" PRIx64 "\"}%s\n", name,
+           res.scores.empty() ? 0 : bits(res.scores.back().score), res.scores.size(), h, last ? "" : ",");
+  };
+  auto timed = [&](const char* name, const UidRelSet& u, const PathSet& a, const PathSet& b, PathSet& r) {
+    const double t0 = now_s();
+    joined_res res = exec.join(u, a, b, r);
+    if (timing) timing->push_back({name, now_s() - t0});
+    return res;
+  };
+  auto parsed1 = exec.createPathSet(in.data1.size());
+  parsed1->load(in.data1);                               // REFERENCE PathSet::load
+  auto zero_set = exec.createPathSet(0);
+  TPathSet paths1, paths2, paths3;
+  if (L >= 1) {
+    paths1 = exec.createPathSet(in.lv[0].count_total_paths());
+    auto z1 = exec.createPathSet(in.idx0.size());
+    auto in1 = parsed1->select(in.idx0);                 // REFERENCE PathSet::select
+    auto r0 = timed("lst1a", in.lv[0], *z1, *in1, *paths1);
+    emit("lst1a", r0, paths1.get(), false);
+    auto z2 = exec.createPathSet(in.idx1.size());
+    auto parsed2 = exec.createPathSet(in.data2.size());
+    parsed2->load(in.data2);
+    auto in2 = parsed2->select(in.idx1);
+    emit("lst1", timed("lst1", in.lv[1], *z2, *in2, *zero_set), nullptr, L == 1);
+  }
+  if (L >= 2) {
+    paths2 = exec.createPathSet(in.lv[2].count_total_paths());
+    auto sel = parsed1->select(in.idx2);
+    emit("lst2", timed("lst2", in.lv[2], *paths1, *sel, *paths2), paths2.get(), L == 2);
+  }
+  if (L >= 3) {
+    paths3 = exec.createPathSet(in.lv[3].count_total_paths());
+    auto sel = parsed1->select(in.idx3);
+    emit("lst3", timed("lst3", in.lv[3], *paths2, *sel, *paths3), paths3.get(), L == 3);
+  }
+  if (L >= 4) emit("lst4", timed("lst4", in.lv[4], *paths3, *paths2, *zero_set), nullptr, L == 4);
+  if (L >= 5) emit("lst5", timed("lst5", in.lv[5], *paths3, *paths3, *zero_set), nullptr, true);
+}
+
+// ---- binary problem ("GCREBIN2", written by geneticscre_amd/harness_io.py write_problem_bin): every ProcessPaths input.
+// The text format of test/test.cpp needs ~20 bytes per table cell: a 5,000-patient table would be half a gigabyte. ----
+template <typename T>
+static bool read_vec(FILE* f, vector<T>& v, int64_t n) { v.resize((size_t)n); return read_exact(f, v.data(), (size_t)n * sizeof(T)); }
+
+static bool read_u8_matrix(FILE* f, vec2d_i& m) {
+  int64_t d[2];
+  if (!read_exact(f, d, sizeof d)) return false;
+  vector<uint8_t> raw;
+  if (!read_vec(f, raw, d[0] * d[1])) return false;
+  m.assign((size_t)d[0], vec_i((size_t)d[1]));
+  for (int64_t r = 0; r < d[0]; r++)
+    for (int64_t c = 0; c < d[1]; c++) m[(size_t)r][(size_t)c] = raw[(size_t)(r * d[1] + c)];
+  return true;
+}
+
+// ref_driver --bin <file> [--time] [--threads N]: the same JSON as the text mode (--time: per-join seconds, digests only)
+static int bin_main(const char* path, bool timing, int threads_override) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", path); return 2; }
+  char magic[8];
+  int32_t h[8];
+  if (!read_exact(f, magic, 8) || memcmp(magic, "GCREBIN2", 8) || !read_exact(f, h, sizeof h)) return 2;
+  const int method = h[0], n_cases = h[1], n_ctrls = h[2], K = h[3], top_k = h[4], L = h[5];
+  const int nthreads = threads_override > -1000 ? threads_override : h[6];
+  JoinExec exec(method == 1 ? "method1" : "method2", n_cases, n_ctrls, K);
+  exec.top_k = top_k;
+  exec.nthreads = nthreads;
+  Inputs in;
+  const int plen[6] = {1, 1, 2, 3, 4, 5};
+  for (int i = 0; i < 6; i++) {
+    int64_t d[2];
+    if (!read_exact(f, d, sizeof d)) return 2;
+    vector<int32_t> src, trg, cnt, sg;
+    vector<int64_t> loc;
+    if (!read_vec(f, src, d[0]) || !read_vec(f, trg, d[0]) || !read_vec(f, cnt, d[0]) || !read_vec(f, loc, d[0]) || !read_vec(f, sg, d[1])) return 2;
+    vector<uid_ref> uv((size_t)d[0]);
+    for (int64_t k = 0; k < d[0]; k++) { uv[k].src = src[k]; uv[k].trg = trg[k]; uv[k].count = cnt[k]; uv[k].location = (st_pathset_size)loc[k]; }
+    in.lv.push_back(with_idx(plen[i], uv, vector<int>(sg.begin(), sg.end())));
+  }
+  vec_i* idx[4] = {&in.idx0, &in.idx1, &in.idx2, &in.idx3};
+  for (auto* v : idx) {
+    int64_t n;
+    vector<int32_t> raw;
+    if (!read_exact(f, &n, 8) || !read_vec(f, raw, n)) return 2;
+    v->assign(raw.begin(), raw.end());
+  }
+  vec2d_i perms;
+  if (!read_u8_matrix(f, in.data1) || !read_u8_matrix(f, in.data2) || !read_u8_matrix(f, perms)) return 2;
+  int64_t td[2];
+  if (!read_exact(f, td, sizeof td)) return 2;
+  vec2d_d table((size_t)td[0], vec_d((size_t)td[1]));
+  for (auto& tr : table) if (!read_exact(f, tr.data(), (size_t)td[1] * 8)) return 2;
+  fclose(f);
+  exec.setValueTable(table);
+  if (K > 0) exec.setPermutedCases(perms);
+  vector<pair<string, double>> secs;
+  printf("{\n");
+  run_sequence(exec, in, L, timing ? &secs : nullptr, timing);
+  if (timing) {
+    printf("  ,\"threads\": %d, \"seconds\": {", nthreads);
+    for (size_t k = 0; k < secs.size(); k++) printf("%s\"%s\": %.6f", k ? ", " : "", secs[k].first.c_str(), secs[k].second);
+    printf("}, \"paths\": {");
+    const char* names[6] = {"lst1a", "lst1", "lst2", "lst3", "lst4", "lst5"};
+    int shown = 0;
+    for (int i = 0; i < 6; i++)
+      if (plen[i] <= L) printf("%s\"%s\": %llu", shown++ ? ", " : "", names[i], (unsigned long long)in.lv[(size_t)i].count_total_paths());
+    printf("}\n");
+  }
+  printf("}\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc == 2 && !strcmp(argv[1], "--selftest")) { printf("ok\n"); return 0; }
   if (argc == 3 && !strcmp(argv[1], "--bench")) return bench_main(argv[2]);
+  if (argc >= 3 && !strcmp(argv[1], "--bin")) {
+    bool timing = false;
+    int threads = -1000;
+    for (int k = 3; k < argc; k++) {
+      if (!strcmp(argv[k], "--time")) timing = true;
+      else if (!strcmp(argv[k], "--threads") && k + 1 < argc) threads = atoi(argv[++k]);
+    }
+    return bin_main(argv[2], timing, threads);
+  }
   if (argc < 6) { fprintf(stderr, "usage: ref_driver <dump.txt> <method1|method2> <iterations> <top_k> <path_length>\n"); return 2; }
   ifstream f(argv[1]);
   const string method = argv[2];
@@ -220,43 +361,17 @@ int main(int argc, char** argv) {
   JoinExec exec(method, num_cases, num_ctrls, iters);
   exec.top_k = top_k;
   exec.nthreads = 0;
-  vector<UidRelSet> lv;
+  Inputs in;
   const int plen[6] = {1, 1, 2, 3, 4, 5};
-  for (int i = 0; i < 6; i++) { auto u = test::read_uids(f); auto s = test::read_ints(f); lv.push_back(with_idx(plen[i], u, s)); }
-  auto idx0 = test::read_ints(f), idx1 = test::read_ints(f), idx2 = test::read_ints(f), idx3 = test::read_ints(f);
-  auto data1 = test::read_data(f), data2 = test::read_data(f), perms = test::read_data(f);
+  for (int i = 0; i < 6; i++) { auto u = test::read_uids(f); auto s = test::read_ints(f); in.lv.push_back(with_idx(plen[i], u, s)); }
+  in.idx0 = test::read_ints(f); in.idx1 = test::read_ints(f); in.idx2 = test::read_ints(f); in.idx3 = test::read_ints(f);
+  in.data1 = test::read_data(f); in.data2 = test::read_data(f);
+  auto perms = test::read_data(f);
   auto table = test::read_vals(f);
   exec.setValueTable(table);
   if (iters > 0) exec.setPermutedCases(perms);
-  auto parsed1 = exec.createPathSet(data1.size());
-  parsed1->load(data1);                                  // REFERENCE PathSet::load
-  auto zero_set = exec.createPathSet(0);
-  TPathSet paths1, paths2, paths3;
   printf("{\n");
-  if (L >= 1) {
-    paths1 = exec.createPathSet(lv[0].count_total_paths());
-    auto z1 = exec.createPathSet(idx0.size());
-    auto in1 = parsed1->select(idx0);                    // REFERENCE PathSet::select
-    auto r0 = exec.join(lv[0], *z1, *in1, *paths1);
-    dump("lst1a", r0, paths1.get(), false);
-    auto z2 = exec.createPathSet(idx1.size());
-    auto parsed2 = exec.createPathSet(data2.size());
-    parsed2->load(data2);
-    auto in2 = parsed2->select(idx1);
-    dump("lst1", exec.join(lv[1], *z2, *in2, *zero_set), nullptr, L == 1);
-  }
-  if (L >= 2) {
-    paths2 = exec.createPathSet(lv[2].count_total_paths());
-    auto in = parsed1->select(idx2);
-    dump("lst2", exec.join(lv[2], *paths1, *in, *paths2), paths2.get(), L == 2);
-  }
-  if (L >= 3) {
-    paths3 = exec.createPathSet(lv[3].count_total_paths());
-    auto in = parsed1->select(idx3);
-    dump("lst3", exec.join(lv[3], *paths2, *in, *paths3), paths3.get(), L == 3);
-  }
-  if (L >= 4) dump("lst4", exec.join(lv[4], *paths3, *paths2, *zero_set), nullptr, L == 4);
-  if (L >= 5) dump("lst5", exec.join(lv[5], *paths3, *paths3, *zero_set), nullptr, true);
+  run_sequence(exec, in, L, nullptr, false);
   printf("}\n");
   return 0;
 }

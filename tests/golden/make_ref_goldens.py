@@ -3,7 +3,10 @@
 
 Run in the build container only (needs /root/reference and g++):
 
-    make -C oracle/ref_partial && python tests/golden/make_ref_goldens.py
+    make -C oracle/ref_partial && python tests/golden/make_ref_goldens.py [out_dir]
+
+(tests/test_oracle.py::test_committed_goldens_regenerate re-runs this into a temporary directory and compares the files
+byte for byte whenever the reference tree is present, so the fixtures cannot drift from their generator again.)
 
 oracle/_ref/ref_driver links the reference's own header-only scoring code (src/methods.h score_permute /
 merge_scores, src/gcre_paths.h PathSet, src/gcre.h need_flip, src/gcre_types.h Score) and its text-dump parser
@@ -23,9 +26,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from geneticscre_amd.harness_io import write_problem  # noqa: E402
-from geneticscre_amd.synth import make_problem, values_table  # noqa: E402
-from helpers import small_table  # noqa: E402
+from geneticscre_amd.harness_io import problem_digest, write_problem, write_problem_bin  # noqa: E402
+from geneticscre_amd.synth import make_problem  # noqa: E402
+from helpers import WIDE_CASES, small_table, wide_problem  # noqa: E402
 
 DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
 OUT = os.path.join(HERE, "ref_cases")
@@ -42,8 +45,8 @@ CASES = [
 ]
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
+def main(out=OUT, wide=True):
+    os.makedirs(out, exist_ok=True)
     index = []
     for name, method, genes, edges, nc, nt, rows, iters, length, top_k, seed, table in CASES:
         tbl = {"small": small_table(nc, nt, seed), "hyper": None, "flat": np.full((nc + 1, nt + 1), 1.5)}[table]
@@ -51,20 +54,38 @@ def main():
         if rows == 0:
             p.perm_cases = np.ones((1, nc + nt), dtype=np.int32)   # unread: iterations == 0
         p.iterations = iters
-        dump = os.path.join(OUT, name + ".txt")
+        dump = os.path.join(out, name + ".txt")
         write_problem(dump, p)
-        out = subprocess.run([DRIVER, dump, method, str(iters), str(top_k), str(length)], check=True,
-                             capture_output=True, text=True).stdout
-        res = json.loads(out)
+        res = json.loads(subprocess.run([DRIVER, dump, method, str(iters), str(top_k), str(length)], check=True,
+                                        capture_output=True, text=True).stdout)
         res["_case"] = {"method": method, "iterations": iters, "top_k": top_k, "path_length": length,
                         "paths": {k: int(v) for k, v in p.levels.n_paths.items()}}
-        with open(os.path.join(OUT, name + ".json"), "w") as f:
+        with open(os.path.join(out, name + ".json"), "w") as f:
             json.dump(res, f, separators=(",", ":"))
         index.append(name)
         print(name, os.path.getsize(dump), "B dump", {k: v for k, v in p.levels.n_paths.items()})
-    with open(os.path.join(OUT, "INDEX.json"), "w") as f:
-        json.dump({"_provenance": __doc__.strip().splitlines()[0], "cases": index}, f, indent=1)
+    wide_index = []
+    if wide:
+        import tempfile
+        for name, (method, genes, edges, nc, nt, perms, length, top_k, seed) in WIDE_CASES.items():
+            p = wide_problem(name)
+            with tempfile.TemporaryDirectory() as tmp:
+                blob = os.path.join(tmp, name + ".gcrebin")
+                write_problem_bin(blob, p)        # tens of MB: the inputs are regenerated from the seed, never committed
+                res = json.loads(subprocess.run([DRIVER, "--bin", blob], check=True, capture_output=True, text=True).stdout)
+            res["_case"] = {"method": method, "iterations": perms, "top_k": top_k, "path_length": length,
+                            "generator": {"genes": genes, "edges": edges, "cases": nc, "ctrls": nt, "seed": seed,
+                                          "table": "gcre_values_table"},
+                            "mask_words": (nc + nt + 63) // 64,
+                            "paths": {k: int(v) for k, v in p.levels.n_paths.items()},
+                            "input_sha256": problem_digest(p)}
+            with open(os.path.join(out, name + ".json"), "w") as f:
+                json.dump(res, f, separators=(",", ":"))
+            wide_index.append(name)
+            print(name, (nc + nt + 63) // 64, "words", {k: v for k, v in p.levels.n_paths.items()})
+    with open(os.path.join(out, "INDEX.json"), "w") as f:
+        json.dump({"_provenance": __doc__.strip().splitlines()[0], "cases": index, "wide_cases": wide_index}, f, indent=1)
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else OUT)

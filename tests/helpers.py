@@ -49,3 +49,45 @@ def load_ref_cases():
                          top_k=c["top_k"], path_length=c["path_length"])
         out.append((name, p, exp))
     return out
+
+
+# ---- goldens at BASELINE mask widths (tests/golden/ref_cases/w*.json) ------------------------------------------------
+# The reference's own scoring code (oracle/ref_partial) run on problems too large to commit as text: 16, 79 and 157 mask
+# words (BASELINE configs[1], [2], [3]), both methods, the hypergeometric value table.  Only the outputs are committed;
+# the inputs are regenerated from the seed by the same generator call, and their SHA-256 is checked against the one
+# recorded when the golden was cut, so a drifting generator fails loudly.
+WIDE_CASES = {
+    # name: method, genes, edges, cases, ctrls, permutations, length, top_k, seed
+    "w16_m1": ("method1", 200, 700, 460, 540, 300, 4, 20, 211),
+    "w16_m2": ("method2", 200, 700, 460, 540, 300, 4, 20, 212),
+    "w79_m1": ("method1", 200, 700, 2400, 2600, 300, 4, 20, 213),
+    "w79_m2": ("method2", 200, 700, 2400, 2600, 300, 4, 20, 214),
+    "w157_m1": ("method1", 200, 700, 4300, 5700, 300, 4, 20, 215),
+    "w157_m2": ("method2", 200, 700, 4300, 5700, 300, 4, 20, 216),
+}
+_WIDE_TABLES: dict = {}
+_WIDE_PROBLEMS: dict = {}
+
+
+def wide_problem(name: str) -> Problem:
+    """The inputs of a wide golden, rebuilt from its seed (cached per session; the 10,000-patient table takes ~15 s)."""
+    if name not in _WIDE_PROBLEMS:
+        from geneticscre_amd import api
+        method, genes, edges, nc, nt, perms, length, top_k, seed = WIDE_CASES[name]
+        if (nc, nt) not in _WIDE_TABLES:
+            _WIDE_TABLES[(nc, nt)] = api.values_table(nc, nt)
+        _WIDE_PROBLEMS[name] = make_problem(genes, edges, nc, nt, perms, length, method=method, top_k=top_k, seed=seed,
+                                            table=_WIDE_TABLES[(nc, nt)])
+    return _WIDE_PROBLEMS[name]
+
+
+def load_wide_case(name: str):
+    """(Problem, expected dict) of a wide golden; fails if the regenerated inputs are not the ones the golden was cut from."""
+    import json
+    import os
+    from geneticscre_amd.harness_io import problem_digest
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cases")
+    exp = json.load(open(os.path.join(d, name + ".json")))
+    p = wide_problem(name)
+    assert problem_digest(p) == exp["_case"]["input_sha256"], f"{name}: the generator no longer reproduces the golden's inputs"
+    return p, exp

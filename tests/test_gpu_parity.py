@@ -158,6 +158,30 @@ def test_hip_matches_reference_scoring_code(name, p, exp, kernel, monkeypatch):
                 assert (r.src[k], r.trg[k]) == (e["src"][k], e["trg"][k]), (name, lvl, k)
 
 
+from helpers import WIDE_CASES, load_wide_case  # noqa: E402
+
+
+@pytest.mark.parametrize("kernel", ["auto", "sparse"])
+@pytest.mark.parametrize("name", list(WIDE_CASES))
+def test_hip_matches_reference_scoring_code_at_baseline_widths(name, kernel, monkeypatch):
+    """The HIP path against outputs of the reference's own scoring code at 16, 79 and 157 mask words (BASELINE
+    configs[1]-[3]) with the hypergeometric table, both methods: reference code <-> GPU, not via the oracle."""
+    set_kernel(monkeypatch, kernel)
+    p, exp = load_wide_case(name)
+    got = api.process_paths(p)
+    every = oracle.process_paths(p, order="canonical", nthreads=8)       # only for "is this score tied among ALL paths?"
+    for lvl in range(1, p.path_length + 1):
+        e, r = exp[f"lst{lvl}"], got[f"lst{lvl}"]
+        all_bits = [f"{int(b):016x}" for b in every[f"lst{lvl}"].all_scores.view(np.uint64)]
+        assert [f"{int(b):016x}" for b in r.scores.view(np.uint64)] == e["scores"], (name, lvl)
+        assert [f"{int(b):08x}" for b in r.null.view(np.uint32)] == e["null"], (name, lvl)
+        assert sorted(zip(e["scores"], e["cases"], e["ctrls"])) == \
+               sorted(zip([f"{int(b):016x}" for b in r.scores.view(np.uint64)], r.cases.tolist(), r.ctrls.tolist()))
+        for k, s in enumerate(e["scores"]):
+            if all_bits.count(s) == 1:
+                assert (r.src[k], r.trg[k]) == (e["src"][k], e["trg"][k]), (name, lvl, k)
+
+
 @pytest.mark.parametrize("name,p,exp", REF_CASES[:4], ids=[c[0] for c in REF_CASES[:4]])
 def test_hip_kept_rows_match_reference(name, p, exp):
     """Rows written by the keep joins (levels 1a, 2, 3) hash to what the reference's PathSet held."""

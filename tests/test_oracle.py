@@ -17,6 +17,7 @@ from geneticscre_amd.synth import make_problem, masks_from_case_or_control
 from helpers import small_table
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = json.load(open(os.path.join(GOLD, "appendix_b_expected.json")))["cases"]
 
 
@@ -207,3 +208,41 @@ def test_oracle_matches_reference_scoring_code(name, p, exp):
         if lvl <= p.path_length:
             assert fnv_rows(got[f"paths{lvl}"]) == exp[key]["kept_hash"], (name, key)
             assert len(got[f"paths{lvl}"]) == exp[key]["kept_rows"]
+
+
+from helpers import WIDE_CASES, load_wide_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(WIDE_CASES))
+def test_oracle_matches_reference_scoring_code_at_baseline_widths(name):
+    """The same, at the mask widths of BASELINE configs[1]-[3] (16, 79, 157 words) with the hypergeometric table, both
+    methods: outputs of the reference's own scoring code on problems regenerated from their seed (only the outputs are
+    committed; the inputs' SHA-256 is checked against the one recorded with the golden)."""
+    p, exp = load_wide_case(name)
+    got = oracle.process_paths(p, order="reference", nthreads=0)
+    for lvl in range(1, p.path_length + 1):
+        e, r = exp[f"lst{lvl}"], got[f"lst{lvl}"]
+        assert [f"{int(b):016x}" for b in r.scores.view(np.uint64)] == e["scores"], (name, lvl)
+        assert r.src.tolist() == e["src"] and r.trg.tolist() == e["trg"], (name, lvl)
+        assert r.cases.tolist() == e["cases"] and r.ctrls.tolist() == e["ctrls"], (name, lvl)
+        assert [f"{int(b):08x}" for b in r.null.view(np.uint32)] == e["null"], (name, lvl)
+    for lvl, key in ((1, "lst1a"), (2, "lst2"), (3, "lst3")):
+        assert fnv_rows(got[f"paths{lvl}"]) == exp[key]["kept_hash"], (name, key)
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference/src") and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_driver"))),
+                    reason="needs the reference tree and the partial reference build (build container only)")
+def test_committed_goldens_regenerate(tmp_path):
+    """tests/golden/make_ref_goldens.py into a temporary directory gives the committed files byte for byte: the fixtures
+    cannot drift from their generator (round 2: a table builder changed after the goldens were cut and nothing noticed)."""
+    import filecmp
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_ref_goldens", os.path.join(ROOT, "tests", "golden", "make_ref_goldens.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(str(tmp_path))
+    committed = os.path.join(ROOT, "tests", "golden", "ref_cases")
+    names = sorted(os.listdir(committed))
+    assert names == sorted(os.listdir(tmp_path))
+    match, mismatch, errors = filecmp.cmpfiles(committed, str(tmp_path), names, shallow=False)
+    assert not mismatch and not errors, (mismatch, errors)
