@@ -210,11 +210,29 @@ def reference_baseline(prob, masks, u, n_uids, p0, p1, threads, port_res):
     finally:
         os.unlink(tmp)
     same = [f"{int(b):08x}" for b in port_res.null.view(np.uint32)] == res["null"]
-    return {"value": res["paths"] * K / res["seconds"], "unit": "scores/s", "cores": threads, "kind": "reference",
-            "sample": f"level-{u.path_length} join, first {n_uids} uids = {res['paths']} joined paths x {K} permutations, "
-                      f"{res['seconds']:.1f} s wall; reference src/methods.h score_permute via {os.path.basename(binary)} "
-                      f"(partial reference build, -O3 AVX-512/AVX2; driver-side thread pool)",
-            "null_maxima_equal_port": same}
+    out = {"value": res["paths"] * K / res["seconds"], "unit": "scores/s", "cores": threads, "kind": "reference",
+           "sample": f"level-{u.path_length} join, first {n_uids} uids = {res['paths']} joined paths x {K} permutations, "
+                     f"{res['seconds']:.1f} s wall; reference src/methods.h score_permute via {os.path.basename(binary)} "
+                     f"(partial reference build, -O3 AVX-512/AVX2; driver-side thread pool)",
+           "null_maxima_equal_port": same}
+    # the same sample through the HIP library: reference code <-> GPU at this mask width and permutation count, every run
+    try:
+        from geneticscre_amd import api
+        from geneticscre_amd.uids import UidRelSet
+        sub = UidRelSet(u.path_length, u.src[:n_uids], u.trg[:n_uids], u.count[:n_uids], u.location[:n_uids], u.signs)
+        ex = api.JoinExec(prob.method, prob.n_cases, prob.n_ctrls, K)
+        try:
+            ex.top_k = prob.top_k
+            ex.set_value_table(table)
+            ex.set_permuted_masks(np.ascontiguousarray(masks[:K], dtype=np.uint64))
+            g = ex.join(sub, ex.from_words(rows0), ex.from_words(rows1))
+            out["null_maxima_equal_gpu"] = [f"{int(b):08x}" for b in g.null.view(np.uint32)] == res["null"]
+            out["best_score_equal_gpu"] = f"{int(g.scores.view(np.uint64)[-1]):016x}" == res["best"]
+        finally:
+            ex.close()
+    except Exception as e:   # reported, never required
+        out["null_maxima_equal_gpu"] = repr(e)
+    return out
 
 
 def end_to_end(prob, masks, device, total_scores):
@@ -241,14 +259,33 @@ def end_to_end(prob, masks, device, total_scores):
             "last_join_profile_ms": lib}
 
 
+def ref_driver_binary():
+    """oracle/_ref/ref_driver(_v4): the partial reference build (travels with the tree; built where /root/reference exists)."""
+    import subprocess
+    for cand in ("ref_driver_v4", "ref_driver"):
+        path = os.path.join(ROOT, "oracle", "_ref", cand)
+        if os.path.exists(path):
+            try:
+                if subprocess.run([path, "--selftest"], capture_output=True, timeout=20).returncode == 0:
+                    return path
+            except (OSError, subprocess.SubprocessError):
+                pass
+    return None
+
+
 def six_join_baseline(cfg, seed, top_k, level_sample, budget_s=10.0):
     """BASELINE.md §3's CPU baseline: the full six-join sequence of the reference harness (test/harness.cpp:121-181:
-    levels 1a, 1b, 2 .. L) through the oracle port, on a network cut down until the run takes ~10 s, at
-    threads = cores and at threads = 0 (the reference's inline mode, src/join_base.cpp:170-171; fewer permutations)."""
+    levels 1a, 1b, 2 .. L) on a network cut down until the run takes ~10 s, at threads = cores and at threads = 0 (the
+    reference's inline mode, src/join_base.cpp:170-171; fewer permutations) -- through the reference's OWN scoring code
+    (oracle/_ref/ref_driver --bin --time: src/methods.h score_permute / merge_scores, src/gcre_paths.h PathSet for all six
+    joins, `kind: "reference"`), with the oracle port beside it on the same input (`port`) and their digests compared."""
+    import subprocess
+    import tempfile
     import oracle
     from geneticscre_amd import synth
+    from geneticscre_amd.harness_io import write_problem_bin
     threads = host_threads()
-    rate = float(level_sample.get("port", level_sample).get("value", 2e9))    # scores/s of the port at `threads`
+    rate = float(level_sample.get("value", 2e9))    # scores/s of the reference's score_permute at `threads`
     K = cfg["perms"]
     best = None
     for genes, edges in ((6000, 40000), (5000, 30000), (4000, 20000), (3000, 12000), (2000, 7000), (1000, 3000)):
@@ -262,15 +299,84 @@ def six_join_baseline(cfg, seed, top_k, level_sample, budget_s=10.0):
     p, paths, genes, edges = best
     rng = np.random.default_rng(seed + 2)
     p.value_table = synth.values_table(cfg["cases"], cfg["ctrls"])
+    binary = ref_driver_binary()
     out = {"network": f"{genes} genes / {edges} relations, {cfg['cases']}+{cfg['ctrls']} patients, path length {cfg['length']}: {paths} joined paths over six joins",
-           "code": "oracle/gcre_oracle.cpp (port of JoinExec, -O3 -march=native)"}
+           "kind": "reference" if binary else "port",
+           "code": (f"reference src/methods.h + src/gcre_paths.h through oracle/_ref/{os.path.basename(binary)} --bin --time (join_base.cpp's members are the "
+                    "driver's: it needs Rcpp)") if binary else "oracle/gcre_oracle.cpp (port of JoinExec, -O3 -march=native): no partial reference build in this tree"}
+
+    def fnv_null(null):
+        h = 1469598103934665603
+        for w in np.asarray(null, dtype=np.float32).view(np.uint32).tolist():
+            h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return f"{h:016x}"
+
     for label, nthreads, k_run in (("threads_eq_cores", threads, K), ("threads_0", 0, max(16, K // max(threads, 1)))):
         p.iterations = k_run
         p.perm_cases = synth.case_or_control(cfg["cases"], cfg["ctrls"], k_run, rng)
-        t0 = time.perf_counter()
-        oracle.process_paths(p, order="reference", nthreads=nthreads)
-        t = time.perf_counter() - t0
-        out[label] = {"value": paths * k_run / t, "unit": "scores/s", "threads": nthreads, "permutations": k_run, "seconds": t}
+        entry = {"unit": "scores/s", "threads": nthreads, "permutations": k_run}
+        ref = None
+        if binary:
+            with tempfile.NamedTemporaryFile(suffix=".gcrebin", delete=False) as f:
+                tmp = f.name
+            try:
+                write_problem_bin(tmp, p, nthreads=nthreads)
+                r = subprocess.run([binary, "--bin", tmp, "--time"], capture_output=True, text=True, timeout=900)
+                if r.returncode == 0:
+                    ref = json.loads(r.stdout)
+            except (OSError, subprocess.SubprocessError, ValueError):
+                ref = None
+            finally:
+                os.unlink(tmp)
+        if ref is not None:
+            t = sum(ref["seconds"].values())
+            entry.update({"value": paths * k_run / t, "seconds": t, "seconds_per_join": ref["seconds"]})
+        if ref is None or label == "threads_eq_cores":
+            t0 = time.perf_counter()
+            port = oracle.process_paths(p, order="reference", nthreads=nthreads)
+            tp = time.perf_counter() - t0
+            if ref is None:
+                entry.update({"value": paths * k_run / tp, "seconds": tp})
+            else:
+                entry["port"] = {"value": paths * k_run / tp, "seconds": tp,
+                                 "what": "oracle/gcre_oracle.cpp on the same input (its time includes packing the inputs; the reference's is its six join calls)"}
+                entry["equal_port"] = all(ref[f"lst{l}"]["null_fnv"] == fnv_null(port[f"lst{l}"].null) and
+                                          ref[f"lst{l}"]["best"] == f"{int(port[f'lst{l}'].scores.view(np.uint64)[-1]):016x}"
+                                          for l in range(1, cfg["length"] + 1))
+        out[label] = entry
+    return out
+
+
+def sensitivity(prob, masks, cfg, seed, device, rates=(0.01, 0.025, 0.05), steps=2):
+    """How the headline holds up when the data gets denser: the same network, patients, masks and table with every gene at
+    1 %, 2.5 % and 5 % carriers (5 % is the reference's own admission limit, R/Utils.R:185-188), one warm-up + `steps` timed
+    passes each.  Reported beside the headline, never part of it."""
+    import dataclasses
+    import torch
+    from geneticscre_amd import api, synth
+    out = {}
+    n = prob.n_cases + prob.n_ctrls
+    for rate in rates:
+        rng = np.random.default_rng(seed + int(rate * 1e4))
+        data1 = synth.variant_matrix(prob.data1.shape[0], n, rng, fixed_rate=rate)
+        p2 = dataclasses.replace(prob, data1=data1, data2=data1[prob.levels.uids["1b"].src])
+        plan = api.ResidentPlan(p2, device=device, packed_masks=masks)
+        try:
+            plan.run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                plan.run()
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / steps
+            tiles = sum(plan.uids[k].total_paths for k in plan.names) * ((prob.iterations + 2047) // 2048)
+            out[f"{rate:g}"] = {"value": plan.total_scores() / t, "unit": "scores/s", "ms_per_step": t * 1e3,
+                                "lookups_per_path_tile": plan.last_profile.get("ie_lookup_tiles", 0) / max(tiles, 1)}
+        finally:
+            plan.close()
+        del data1, p2
+    out["what"] = ("configs[2] with every gene at the given carrier rate instead of 0.05 * U^3 (mean 1.25 %); same network, patients, "
+                   "permutation masks and value table as the headline; not part of `value`")
     return out
 
 
@@ -293,6 +399,7 @@ def main():
                     help="N > 1: strong = the same workload for every N (K permutations in total), weak = K per GPU (K x N)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the cold one-shot gcre_process_paths measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the 1 % / 2.5 % / 5 % carrier-rate passes")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the extra passes with kept inspections")
     ap.add_argument("--no-one-gpu-reference", action="store_true",
                     help="N > 1: skip the two passes of the whole workload on rank 0's GPU alone")
@@ -537,6 +644,11 @@ def main():
             line["end_to_end"] = end_to_end(prob, masks, local_rank, total_scores)
         except Exception as e:   # reported, never required
             line["end_to_end"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_sensitivity and masks is not None and args.config == "roofline" and not args.carrier_rate:
+        try:
+            line["sensitivity"] = sensitivity(prob, masks, cfg, args.seed, local_rank)
+        except Exception as e:   # reported, never required
+            line["sensitivity"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and masks is None:
         line["cpu_baseline"] = {"skipped": "device-drawn masks at this scale; the baseline is timed on configs[2]"}
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:

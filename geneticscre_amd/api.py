@@ -93,7 +93,7 @@ EXPORTS = [
     "gcre_process_paths", "gcre_resolve_count_locs", "gcre_build_levels", "gcre_levels_free", "gcre_values_table",
     "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask", "gcre_uids_set_reduced",
     "gcre_set_perm_window", "gcre_plan_perm_window", "gcre_process_paths_devices",
-    "gcre_set_inspect_cache", "gcre_drop_inspections", "gcre_build_flags",
+    "gcre_set_inspect_cache", "gcre_drop_inspections", "gcre_build_flags", "gcre_device_count",
 ]
 
 

@@ -197,7 +197,7 @@ struct gcre_ctx {
   // the top-k selection of a chunk only reads the keys its inspector wrote: it runs beside the warm-up slice and the
   // null kernel on a stream of its own (GCRE_SELECT_STREAM=0: on the main stream, as in round 1)
   hipStream_t sel_stream = nullptr;
-  hipEvent_t ev_sel = nullptr;
+  hipEvent_t ev_sel = nullptr, ev_sel_done = nullptr;
   bool sel_async = true;
   SelectState h_sel{};               // where the digit passes' state lands (outlives any one chunk: the copy is asynchronous)
   std::string err;
@@ -1867,6 +1867,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ran_sparse = true;
         } while (false);
         if (redo) {
+          // the abandoned digit passes may still be reading the keys the relaunched inspector is about to rewrite
+          if (sel_begun && sel_on != st) {
+            HIP_TRY(c, hipEventRecord(c->ev_sel_done, sel_on));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_sel_done, 0));
+          }
           next = cb;   // same chunk again, now against paths1 itself
           continue;
         }
@@ -2000,6 +2005,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             if (rc != GCRE_OK) return rc;
           }
           if (int rc2 = queue_winners(s0, nsel, win, sel_on)) return rc2;
+          // whatever still runs on the selection stream reads this chunk's keys and rows: the next chunk's inspector (on the
+          // main stream) rewrites them, so it queues behind an event -- not behind "the results are discarded anyway"
+          if (sel_on != st) {
+            HIP_TRY(c, hipEventRecord(c->ev_sel_done, sel_on));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_sel_done, 0));
+          }
         }
         if (win.n > 0) {
           const auto tw0 = std::chrono::steady_clock::now();
@@ -2118,6 +2129,10 @@ int gcre_abi_version(void) { return GCRE_ABI_VERSION; }
 #define GCRE_BUILD_FLAGS ""
 #endif
 const char* gcre_build_flags(void) { return GCRE_BUILD_FLAGS; }
+int gcre_device_count(void) {
+  int n = 0;
+  return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? n : 0;
+}
 
 const char* gcre_last_error(const gcre_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -2177,6 +2192,7 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&c->sel_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_sel_done, hipEventDisableTiming) == hipSuccess;
   if (const char* e = std::getenv("GCRE_SELECT_STREAM")) c->sel_async = std::atoi(e) != 0;
   ok = ok && hipMalloc((void**)&c->d_case_mask, (size_t)g.Wp * 8) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_max_tot, 32) == hipSuccess;
@@ -2236,6 +2252,7 @@ void gcre_destroy(gcre_ctx* c) {
   if (c->sel_stream) (void)hipStreamSynchronize(c->sel_stream);
   if (c->sel_stream) (void)hipStreamDestroy(c->sel_stream);
   if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
+  if (c->ev_sel_done) (void)hipEventDestroy(c->ev_sel_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -2609,6 +2626,10 @@ int gcre_uids_set_reduced(gcre_uids* u, const gcre_pathset* reduced, const int32
   u->d_red_index = nullptr;
   u->red = nullptr;
   u->n_red_index = 0;
+  // what the inspector left for this index was computed under the old hint (the cache key names the reduced SET, not the
+  // index contents): a replay would skip the device-side check of the new one
+  u->insp_valid = false;
+  u->insp.clear();
   if (!reduced) return GCRE_OK;
   if (reduced->ctx != c || !index || n < 0) return fail(c, GCRE_ERR_ARG, "bad reduced operand");
   for (int64_t i = 0; i < n; i++)
@@ -2755,7 +2776,11 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
         double unit = 2e6;
         if (const char* e = std::getenv("GCRE_EXCHANGE_UNIT")) unit = std::atof(e);
         const double work = (double)u->total / in->shard_world * (double)((pp_window + kSparseTile - 1) / kSparseTile);
-        if (unit > 0 && work >= 2 * unit && c->d_hub_null.reserve((size_t)c->g.Kpad + 64) == hipSuccess) {
+        if (unit > 0 && work >= 2 * unit) {
+          // the number of exchanges must be the same on every device BY CONSTRUCTION: a device that cannot get its buffer
+          // fails the call (its thread then fails the hub) instead of silently joining with none -- the others would wait
+          // for it for ever, or pair their round with its next join
+          if (c->d_hub_null.reserve((size_t)c->g.Kpad + 64) != hipSuccess) return fail(c, GCRE_ERR_DEVICE, "no memory for the exchange buffer");
           jp.exchanges = (int)std::min(8.0, std::floor(std::log2(work / unit)));
           jp.d_null_out = c->d_hub_null.p;
           jp.exchange_user = c;

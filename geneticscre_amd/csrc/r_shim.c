@@ -32,6 +32,7 @@ static struct {
   void* handle;
   int (*process_paths_devices)(int, int, int, int, int, const int*, int, const gcre_pp_input*, gcre_result[5], char*, size_t);
   void (*result_free)(gcre_result*);
+  int (*device_count)(void);
   int (*resolve)(const int32_t*, int64_t, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t*, int64_t*);
 } G;
 
@@ -48,6 +49,7 @@ static void load_abi(void) {
   } while (0)
   SYM(process_paths_devices, "gcre_process_paths_devices");
   SYM(result_free, "gcre_result_free");
+  SYM(device_count, "gcre_device_count");
   SYM(resolve, "gcre_resolve_count_locs");
 #undef SYM
 }
@@ -148,7 +150,7 @@ SEXP _geneticsCRE_ProcessPaths(
     SEXP inds1, SEXP inds1b, SEXP inds2, SEXP inds3, SEXP data1, SEXP data2, SEXP value_table,
     SEXP num_cases, SEXP num_ctrls, SEXP top_k, SEXP iterations, SEXP perm_cases, SEXP method, SEXP path_length,
     SEXP nthreads) {
-  (void)src1; (void)src1b; (void)src2; (void)src3; (void)src4; (void)src5; (void)nthreads;
+  (void)src1; (void)src1b; (void)src2; (void)src3; (void)src4; (void)src5;
   int np = 0;   /* coerced copies, released together */
   load_abi();
   const int nc = Rf_asInteger(num_cases), nt = Rf_asInteger(num_ctrls), K = Rf_asInteger(iterations);
@@ -188,18 +190,30 @@ SEXP _geneticsCRE_ProcessPaths(
   in.perm_col_major = 1;
   in.path_length = Rf_asInteger(path_length);
 
-  /* Every GPU of the node by default, like the reference takes `nthreads` cores (wrapper.cpp:189): GCRE_DEVICES = "all"
-   * or a comma-separated list of device ids ("0" = the one-GPU behaviour).  The call creates and releases its contexts
-   * itself: nothing native is alive when an R error (longjmp) can happen below. */
+  /* Devices.  ONE by default (device 0): the several-GPU path (gcre_process_paths_devices with N > 1) has only been
+   * rehearsed on a one-GPU box, so it is opt-in until it has run on a real node.  GCRE_DEVICES = "all" takes every GPU of
+   * the node, a comma-separated list takes those ids.  `nthreads` -- the reference's worker count, wrapper.cpp:189 -- caps
+   * the number of devices the call may take when it is positive (GWASPA(nthreads = 1) never takes a second GPU); R passes
+   * -1 for nthreads = NA (ProcessPaths.R:106), which leaves the choice to GCRE_DEVICES.  The call creates and releases its
+   * contexts itself: nothing native is alive when an R error (longjmp) can happen below. */
   int devs[64], ndev = 0;
+  const int cap = Rf_asInteger(nthreads);
   const char* dl = getenv("GCRE_DEVICES");
-  if (dl && strcmp(dl, "all") != 0)
+  if (!dl || !*dl) {
+    devs[ndev++] = 0;
+  } else if (strcmp(dl, "all") == 0) {
+    ndev = G.device_count();
+    if (ndev > 64) ndev = 64;
+    for (int i = 0; i < ndev; i++) devs[i] = i;
+  } else {
     for (const char* q = dl; *q && ndev < 64;) {
       devs[ndev++] = atoi(q);
       q = strchr(q, ',');
       if (!q) break;
       q++;
     }
+  }
+  if (cap > 0 && ndev > cap) ndev = cap;
   gcre_result res[5];
   char msg[512] = "";
   const int rc = G.process_paths_devices(m, nc, nt, K, Rf_asInteger(top_k), ndev ? devs : NULL, ndev, &in, res, msg, sizeof msg);

@@ -108,6 +108,7 @@ int gcre_abi_version(void);
 /* the extra compiler flags the library was built with ("" for the shipped build): a diagnostics build that switches parts of
    a kernel off for a timing experiment (GCRE_*_NO*, results are wrong) is recognisable, __graft_entry__.smoke() asserts "" */
 const char* gcre_build_flags(void);
+int gcre_device_count(void);   /* gfx950 devices visible to the process (0 when there is none: gcre_create then fails) */
 
 int gcre_set_top_k(gcre_ctx* ctx, int top_k);        /* JoinExec::top_k, src/gcre.h:120 (default 12) */
 int gcre_width_ul(const gcre_ctx* ctx);              /* 64-bit words per case/control mask, ceil(n/64) */

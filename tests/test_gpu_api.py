@@ -251,6 +251,47 @@ def test_device_permutation_masks(stratified):
     np.testing.assert_array_equal(a.null.view(np.uint32), b.null.view(np.uint32))
 
 
+@pytest.mark.parametrize("stratified", [False, True])
+def test_device_permutation_masks_are_uniform(stratified):
+    """A biased sampler would pass the reproduction test above: p-values are only as good as these permutations.  Over
+    K = 20,000 device-drawn masks every patient must be a case with the frequency of its stratum (chi-square over the
+    patients), and pairs of patients must be cases together as often as sampling without replacement says
+    (R/Utils.R:22-46: a uniform permutation of the labels inside each stratum)."""
+    nc, nt, K = 70, 110, 20000
+    n = nc + nt
+    strata = (np.arange(n) * 5 % 4).astype(np.int32) if stratified else np.zeros(n, np.int32)
+    ex = api.JoinExec("method1", nc, nt, K)
+    ex.generate_permutations(20261004, strata if stratified else None)
+    W = (n + 63) // 64
+    words = np.stack([ex.perm_mask(r) for r in range(K)]).astype(np.uint64)                    # K x W
+    bits = np.unpackbits(words.view(np.uint8).reshape(K, W * 8), axis=1, bitorder="little")[:, :n].astype(np.int64)
+    assert (bits.sum(axis=1) == nc).all()
+    is_case = np.arange(n) < nc
+    chi, dof = 0.0, 0
+    for s_ in np.unique(strata):
+        sel = np.flatnonzero(strata == s_)
+        m, k = len(sel), int(is_case[sel].sum())
+        assert (bits[:, sel].sum(axis=1) == k).all()                # the stratum keeps its number of cases
+        if k == 0 or k == m:
+            continue
+        pr = k / m
+        obs = bits[:, sel].sum(axis=0)
+        # indicators inside one permutation are negatively correlated (their sum is fixed): the statistic is chi-square with
+        # m - 1 degrees of freedom after the finite-population factor (m - 1) / m
+        chi += float((((obs - K * pr) ** 2) / (K * pr * (1 - pr))).sum()) * (m - 1) / m
+        dof += m - 1
+        # pairs: both cases with probability k (k - 1) / (m (m - 1))
+        both = (bits[:, sel[0]] & bits[:, sel[1]]).sum() + (bits[:, sel[2]] & bits[:, sel[-1]]).sum()
+        p2 = k * (k - 1) / (m * (m - 1))
+        assert abs(both - 2 * K * p2) < 6 * np.sqrt(2 * K * p2 * (1 - p2)), (s_, both, 2 * K * p2)
+    assert abs(chi - dof) < 5 * np.sqrt(2 * dof), (chi, dof)
+    # consecutive permutations are not correlated either: the number of patients that are cases in both r and r + 1
+    same = (bits[:-1] & bits[1:]).sum(axis=1)
+    if not stratified:
+        mean = nc * nc / n
+        assert abs(same.mean() - mean) < 6 * np.sqrt(mean) / np.sqrt(K - 1) * 2
+
+
 def _gwaspa_case(seed, n_genes=60, n_edges=200, nc=48, nt=52):
     """A dataset + knowledge base with extra genes on either side and one planted 3-gene pathway whose union of
     carriers is (almost) all cases."""

@@ -98,6 +98,26 @@ def test_config3_geometry_matches_oracle(config3_small, kernel, monkeypatch):
             assert_same_result(got[name], want[lst])
 
 
+@pytest.fixture(scope="module")
+def config3_small_hyper():
+    nc = nt = 5000
+    p = make_problem(150, 650, nc, nt, 4500, 4, method="method1", top_k=40, seed=33, table=api.values_table(nc, nt))
+    return p, oracle.process_paths(p, order="canonical", nthreads=8)
+
+
+@pytest.mark.parametrize("kernel", ["auto", "ie-quad", "sparse"])
+def test_config3_geometry_with_the_hypergeometric_table(config3_small_hyper, kernel, monkeypatch):
+    """The same geometry on the real -log hypergeometric table (gcre_values_table): the pruning ladder's intervals at 157
+    words are checked on the table the product uses, not only on the smooth chi-square stand-in."""
+    p, want = config3_small_hyper
+    set_mode(monkeypatch, kernel)
+    monkeypatch.setenv("GCRE_WINDOW_TILES", "2")
+    got, prof, windows = run_plan(p)
+    for name, lst in LST.items():
+        if name in got:
+            assert_same_result(got[name], want[lst])
+
+
 def test_config3_full_size_two_algorithms_agree(monkeypatch):
     """BASELINE configs[3] as bench.py builds it (17,000 genes / 200,000 relations, 10,000 patients, 100,000
     permutations drawn on the device, length 4: 2.85e12 scores per pass): inclusion-exclusion (default) and delta
@@ -132,6 +152,23 @@ def test_config4_geometry_matches_oracle(config4_small, kernel, monkeypatch):
     """782 words per half, signed method, level 5 (paths3 x paths3), K = 2,300 = two tiles."""
     p, want = config4_small
     assert (p.n_cases + p.n_ctrls + 63) // 64 == 782
+    set_mode(monkeypatch, kernel)
+    got, prof, _ = run_plan(p)
+    for name, lst in LST.items():
+        assert_same_result(got[name], want[lst])
+
+
+@pytest.fixture(scope="module")
+def config4_small_hyper():
+    nc, nt = 2000, 48000
+    p = make_problem(45, 150, nc, nt, 2300, 5, method="method2", top_k=30, seed=44, table=api.values_table(nc, nt))
+    return p, oracle.process_paths(p, order="canonical", nthreads=8)
+
+
+@pytest.mark.parametrize("kernel", ["auto", "sparse"])
+def test_config4_geometry_with_the_hypergeometric_table(config4_small_hyper, kernel, monkeypatch):
+    """782 words per half, signed method, on the real hypergeometric table (2,000 + 48,000 patients)."""
+    p, want = config4_small_hyper
     set_mode(monkeypatch, kernel)
     got, prof, _ = run_plan(p)
     for name, lst in LST.items():
