@@ -924,6 +924,14 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
   static_assert(L >= 8 && L <= 16, "8 to 16 counter planes");
   typedef u32 __attribute__((ext_vector_type(8))) u32x8;
   __shared__ u32 nmax_lds[kIeWaves][32 * 64];
+  // Look-ups are QUEUED, not made where they are found (round 3).  A look-up is two dependent-latency f64 gathers into
+  // 100-MB tables; made on the spot -- one or two permutations of one path at a time -- the wave sat out a full memory round
+  // trip per path (with the look-ups compiled out the signed pass's null kernels took 35 instead of 82 ms).  Here a
+  // permutation that fails both rectangles only leaves (cell of F, cell of G, slot of its maximum) in the wave's LDS queue;
+  // when 64 are waiting (or the tile ends) every lane takes one, and ONE round trip serves 64 look-ups.  Maxima may lag a
+  // queue behind: a threshold read meanwhile is only lower, never wrong.
+  constexpr u32 kLqCap = 128u;
+  __shared__ u32 lq_lds[kIeWaves][3][kLqCap];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane4 = (u32)lane * 4u;
@@ -931,6 +939,20 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
   for (int q = 0; q < 32; q++) nm[q * 64] = 0u;
   const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
+  u32 (*lq)[kLqCap] = lq_lds[wave];
+  u32 lq_n = 0u;   // entries waiting (wave-uniform)
+  auto lq_drain = [&]() {
+    for (u32 base = 0u; base < lq_n; base += 64u) {
+      const u32 i = base + (u32)lane;
+      if (i < lq_n) {
+        const double f64 = a.d64[lq[0][i]] + a.d64[lq[1][i]];   // vtmax[tp][a] + vtmax[tn][b], methods.h:227
+        float f = (float)f64;
+        f = (f > 0.0f) ? f : 0.0f;
+        __hip_atomic_fetch_max(nmax_lds[wave] + lq[2][i], __float_as_uint(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+    lq_n = 0u;
+  };
 
   int cur_kt = -1;
   u32 valid = 0u;
@@ -969,6 +991,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
     lad_b = (u32)rb * (u32)a.ladder_stride;
   };
   auto flush_tile = [&]() {
+    lq_drain();
     if (cur_kt >= 0) {
       u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
 #pragma unroll 8
@@ -1210,30 +1233,26 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
         u32 m = (pa | nb_) & (pb | na) & valid;
         if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
         n_slow++;
-        const double* dp = a.d64 + sp_diag_offset(rdlane(totv[0], t));
-        const double* dn = a.d64 + sp_diag_offset(rdlane(totv[1], t));
-        while (m != 0u) {
-          u32 bb[4];
-          double sp[4], sn[4];
+        const u32 dp = sp_diag_offset(rdlane(totv[0], t)), dn = sp_diag_offset(rdlane(totv[1], t));
+        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {   // one permutation per lane and round
+          if (lq_n + 64u > kLqCap) lq_drain();
+          const bool has = m != 0u;
+          const u32 bb = has ? (u32)__builtin_ctz(m) : 0u;
+          m &= m - 1u;
+          u32 ca = 0u, cb = 0u;
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            bb[k] = m ? (u32)__builtin_ctz(m) : bb[k ? k - 1 : 0];   // exhausted: repeat the last one (max is idempotent)
-            m &= m - 1u;
-            u32 ca = 0u, cb = 0u;
-#pragma unroll
-            for (int l = 0; l < L; l++) {
-              ca |= ((C[0][l] >> bb[k]) & 1u) << l;
-              cb |= ((C[1][l] >> bb[k]) & 1u) << l;
-            }
-            sp[k] = dp[ca];
-            sn[k] = dn[cb];
+          for (int l = 0; l < L; l++) {
+            ca |= ((C[0][l] >> bb) & 1u) << l;
+            cb |= ((C[1][l] >> bb) & 1u) << l;
           }
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float f = (float)(sp[k] + sn[k]);
-            f = (f > 0.0f) ? f : 0.0f;
-            __hip_atomic_fetch_max(nm + bb[k] * 64, __float_as_uint(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          const u64 hm = __builtin_amdgcn_ballot_w64(has);
+          const u32 pos = lq_n + __builtin_amdgcn_mbcnt_hi((u32)(hm >> 32), __builtin_amdgcn_mbcnt_lo((u32)hm, 0u));
+          if (has) {
+            lq[0][pos] = dp + ca;
+            lq[1][pos] = dn + cb;
+            lq[2][pos] = bb * 64u + (u32)lane;
           }
+          lq_n += (u32)__builtin_popcountll(hm);
         }
         dirty = true;
       }

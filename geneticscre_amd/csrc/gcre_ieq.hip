@@ -50,12 +50,26 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
   typedef u32 __attribute__((ext_vector_type(8))) u32x8;
   __shared__ u32 nmax_lds[kIeWaves][32 * 64];   // the waves' running maxima [bit][lane]
   __shared__ u32 wq_state[kIeWaves][8];
+  // look-ups are queued (cell of the table, slot of the maximum) and made 64 at a time: one memory round trip per 64
+  // look-ups instead of one per path (as k_null_ie_m2; a threshold read before a drain is only lower, never wrong)
+  constexpr u32 kLqCap = 128u;
+  __shared__ u32 lq_lds[kIeWaves][2][kLqCap];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane4 = (u32)lane * 4u;
   u32* nm = nmax_lds[wave] + lane;
 #pragma unroll
   for (int q = 0; q < 32; q++) nm[q * 64] = 0u;
+  u32 (*lq)[kLqCap] = lq_lds[wave];
+  u32 lq_n = 0u;   // entries waiting (wave-uniform)
+  auto lq_drain = [&]() {
+    for (u32 base = 0u; base < lq_n; base += 64u) {
+      const u32 i = base + (u32)lane;
+      if (i < lq_n)
+        __hip_atomic_fetch_max(nmax_lds[wave] + lq[1][i], ((const u32*)a.t32)[lq[0][i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_max_u32
+    }
+    lq_n = 0u;
+  };
   // Launch constants that steer control flow or end up in buffer descriptors, pinned to scalar registers: the compiler
   // re-loads kernel arguments on both sides of the `lane == 0` branch around the ticket atomic, and whatever is derived
   // from such a pair counts as divergent (waterfall loops around buffer loads, vector-register loop counters).
@@ -104,6 +118,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
     lad_base = (u32)j * k_lstride;
   };
   auto flush_tile = [&]() {
+    lq_drain();
     if (cur_kt >= 0) {
       u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
 #pragma unroll 8
@@ -484,21 +499,22 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
         if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) return;
         n_slow++;
         dirty = true;
-        const u32* diag_g = (const u32*)a.t32 + sp_diag_offset(it.tot);
-        while (m != 0u) {
-          u32 bb[4], vv[4];
+        const u32 diag = sp_diag_offset(it.tot);
+        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {   // one permutation per lane and round
+          if (lq_n + 64u > kLqCap) lq_drain();
+          const bool has = m != 0u;
+          const u32 bb = has ? (u32)__builtin_ctz(m) : 0u;
+          m &= m - 1u;
+          u32 cnt = 0u;
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            bb[k] = m ? (u32)__builtin_ctz(m) : bb[k ? k - 1 : 0];   // exhausted: repeat the last one (max is idempotent)
-            m &= m - 1u;
-            u32 cnt = 0u;
-#pragma unroll
-            for (int l = 0; l < L; l++) cnt |= ((C[l] >> bb[k]) & 1u) << l;
-            vv[k] = diag_g[cnt];
+          for (int l = 0; l < L; l++) cnt |= ((C[l] >> bb) & 1u) << l;
+          const u64 hm = __builtin_amdgcn_ballot_w64(has);
+          const u32 pos = lq_n + __builtin_amdgcn_mbcnt_hi((u32)(hm >> 32), __builtin_amdgcn_mbcnt_lo((u32)hm, 0u));
+          if (has) {
+            lq[0][pos] = diag + cnt;
+            lq[1][pos] = bb * 64u + (u32)lane;
           }
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            __hip_atomic_fetch_max(nm + bb[k] * 64, vv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_max_u32
+          lq_n += (u32)__builtin_popcountll(hm);
         }
       };
 #pragma unroll
