@@ -160,13 +160,17 @@ struct ExchangeHub {
   uint64_t gen = 0;
   bool failed = false;
   std::vector<float> acc, result;
-  int reduce(std::vector<float>& mine) {   // in: this device's maxima; out: the MAX over all devices
+  uint64_t round_tag = 0;
+  // tag = (level, permutation window, ordinal of the exchange inside the join): every device of a round must bring the same
+  // one -- a device that skipped or repeated an exchange would otherwise MAX another level's maxima into the thresholds
+  int reduce(std::vector<float>& mine, uint64_t tag) {   // in: this device's maxima; out: the MAX over all devices
     std::unique_lock<std::mutex> lk(m);
     if (failed) return 1;
     if (arrived == 0) {
       acc = mine;
+      round_tag = tag;
     } else {
-      if (acc.size() != mine.size()) { failed = true; cv.notify_all(); return 1; }
+      if (acc.size() != mine.size() || tag != round_tag) { failed = true; cv.notify_all(); return 1; }
       for (size_t i = 0; i < mine.size(); i++) acc[i] = std::max(acc[i], mine[i]);
     }
     if (++arrived == n) {
@@ -233,6 +237,7 @@ struct gcre_ctx {
   bool insp_cache = false;           // gcre_set_inspect_cache: a join's inspector output stays with its join index
   ExchangeHub* hub = nullptr;        // set by gcre_process_paths_devices for the duration of a call
   DevBuf<float> d_hub_null;          // the maxima this device hands to the hub
+  int hub_level = 0, hub_round = 0;  // what the next exchange of this device is: part of the hub's round tag
   // permutation window [win_k0, win_k0 + win_K): what a join scores.  The whole range by default; gcre_set_perm_window
   // narrows it so that the count planes of the kept sets (one per 2048-permutation tile) fit in device memory
   int win_k0 = 0, win_K = 0;
@@ -2784,12 +2789,15 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
           jp.exchanges = (int)std::min(8.0, std::floor(std::log2(work / unit)));
           jp.d_null_out = c->d_hub_null.p;
           jp.exchange_user = c;
+          c->hub_level = lvi;          // 0..5 = levels 1a, 1b, 2, 3, 4, 5
+          c->hub_round = 0;
           jp.exchange = [](void* user, void* d_null, int32_t k0, int32_t k1) -> int {
             gcre_ctx* cc = (gcre_ctx*)user;
             std::vector<float> v((size_t)std::max(k1 - k0, 0));
             if (v.empty()) return 0;
             if (hipMemcpy(v.data(), d_null, v.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { cc->hub->fail(); return 1; }
-            if (cc->hub->reduce(v) != 0) return 1;
+            const uint64_t tag = ((uint64_t)(uint32_t)cc->hub_level << 48) ^ ((uint64_t)(uint32_t)k0 << 16) ^ (uint64_t)(cc->hub_round++ & 0xffff);
+            if (cc->hub->reduce(v, tag) != 0) return 1;
             return hipMemcpy(d_null, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
           };
         }

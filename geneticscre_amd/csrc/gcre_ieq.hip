@@ -25,6 +25,9 @@ namespace gcre {
 // segments at four waves per SIMD beat four at three (25.9 vs 27.4 ms of null kernels per pass on configs[2]: the prologue
 // and the exact pass wait on memory, a fourth wave covers more of that than sharing a plane load four ways saves);
 // four segments at four waves spill (128 VGPRs), three at four do too.
+#ifndef GCRE_REFINE_MAX
+#define GCRE_REFINE_MAX 2   // flagged permutations per lane up to which the filter takes its second look (tuning builds)
+#endif
 #ifndef GCRE_QSEGS
 #define GCRE_QSEGS 2
 #endif
@@ -85,7 +88,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
   u32 valid = 0u;
   u32 lad_base = (k_lad_mode == 0u) ? 0u : ((u32)kLadderLevels - 1u + k_lad_mode) * k_lstride;
   const u32 lad_keep = (u32)kLadderLevels * k_lstride;
-  bool dirty = false;
   u32 n_slow = 0u;
 #ifdef GCRE_IE_TIMING
   u64 tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // header + loads issued, base counters, filter intervals, filter pass, exact pass, exchange, total, quads
@@ -95,7 +97,11 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
 
   // publish the wave's maxima, read everybody's, set the threshold level to the smallest running maximum of the tile's
   // live permutations (a stale read only lowers it: still exact)
-  auto exchange = [&]() {
+  // publish the wave's maxima, read everybody's, set the threshold level to the smallest running maximum of the tile's
+  // live permutations (a stale read only lowers it: still exact).  The merged values stay in LDS: nm[] is then the best
+  // maximum this wave KNOWS of every permutation of the tile (its own finds + the others' as of the last exchange), which
+  // is what the per-permutation second look of the filter (refine, below) tests against.
+  auto merge_global = [&](bool want_theta) {
     u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
     __amdgpu_buffer_rsrc_t nb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.null_bits + (size_t)cur_kt * 2048), 0, 8192, 0x00020000);
     u32x4 g4[8];
@@ -106,12 +112,16 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
     for (int q = 0; q < 32; q++) {
       const u32 g = g4[q >> 2][q & 3];
       const u32 own = nm[q * 64];
-      if (dirty && own > g) atomicMax(out + q, own);
+      if (own > g) atomicMax(out + q, own);     // only what this wave raised itself can be above the global value
       const u32 v = own > g ? own : g;
+      nm[q * 64] = want_theta ? v : 0u;         // the tile ends: the next tile starts from nothing
       if ((valid >> q) & 1u) lo = v < lo ? v : lo;
     }
-    dirty = false;
-    u32 theta = __builtin_amdgcn_readfirstlane(wave_min_u32(lo));
+    return lo;
+  };
+  auto exchange = [&]() {
+    lq_drain();
+    u32 theta = __builtin_amdgcn_readfirstlane(wave_min_u32(merge_global(true)));
     if (theta == 0xffffffffu) theta = 0u;
     int j = (int)(__uint_as_float(theta) * (float)kLadderPerUnit);
     j = j < 0 ? 0 : (j > kLadderLevels - 1 ? kLadderLevels - 1 : j);
@@ -119,18 +129,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
   };
   auto flush_tile = [&]() {
     lq_drain();
-    if (cur_kt >= 0) {
-      u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
-#pragma unroll 8
-      for (int q = 0; q < 32; q++) {
-        const u32 own = nm[q * 64];
-        if (own != 0u) {
-          atomicMax(out + q, own);
-          nm[q * 64] = 0u;
-        }
-      }
-    }
-    dirty = false;
+    if (cur_kt >= 0) (void)merge_global(false);
   };
 
   WorkQueue wq;
@@ -390,7 +389,53 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
           blo = borrow3(w, kl, blo);    // W < lo + ov
           bhi = borrow3(kh, w, bhi);    // W > hi
         }
-        if (__builtin_amdgcn_ballot_w64(((blo | bhi) & valid) != 0u) != 0ull) todo[g] |= 1ull << t;
+        u32 fm = (blo | bhi) & valid;
+        if (__builtin_amdgcn_ballot_w64(fm != 0u) == 0ull) return;
+        // ---- a second look, permutation by permutation.  The interval above belongs to the LOWEST running maximum of the
+        // tile's 2048 permutations; a flagged permutation only matters if its count can leave the (wider) interval of its
+        // OWN maximum as far as this wave knows it (nm[], refreshed at every exchange).  count = W - S with 0 <= S <= ov, so
+        // [W - ov, W] inside that interval settles it without a mask row: most flagged paths end here instead of in the
+        // exact pass (a path costs ~300 instructions there).  Overlap lists only, thresholds from the maxima only. ----
+        const u32 info = rdlane(infov[g], t);
+        // (a path with many flagged permutations -- dense genotypes, where the margin eats the interval -- is not worth
+        // the look: it goes to the exact pass as before)
+        if (k_lad_mode == 0u && (info & 1u) != 0u && __builtin_amdgcn_ballot_w64(__builtin_popcount(fm) > GCRE_REFINE_MAX) == 0ull) {
+          const u32 ov = (info & kLinfoLenMask) - (info >> 28);
+          const u32* lad_t = a.ladder + rdlane(totv[g], t);
+          u32 Wp[L];
+          {
+            u32 c2 = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+              if (l < LZ) {
+                Wp[l] = xor3(Bg[l], Z[l < LZ ? l : 0], c2);
+                c2 = majority(Bg[l], Z[l < LZ ? l : 0], c2);
+              } else {
+                Wp[l] = Bg[l] ^ c2;
+                c2 = Bg[l] & c2;
+              }
+            }
+          }
+          bool unsafe = false;
+          while (__builtin_amdgcn_ballot_w64(fm != 0u) != 0ull) {   // one flagged permutation per lane and round
+            const bool has = fm != 0u;
+            const u32 bb = has ? (u32)__builtin_ctz(fm) : 0u;
+            fm &= fm - 1u;
+            u32 cnt = 0u;
+#pragma unroll
+            for (int l = 0; l < L; l++) cnt |= ((Wp[l] >> bb) & 1u) << l;
+            if (has) {
+              int j = (int)(__uint_as_float(nm[bb * 64]) * (float)kLadderPerUnit);
+              j = j < 0 ? 0 : (j > kLadderLevels - 1 ? kLadderLevels - 1 : j);
+              const u32 lh = lad_t[(u32)j * k_lstride];
+              const u32 lo = lh & 0xffffu, hi = lh >> 16;
+              // every count in [max(0, W - ov), W] inside [lo, hi]?  (counts are never negative: lo = 0 needs no margin)
+              if (cnt > hi || (lo != 0u && cnt < lo + ov)) unsafe = true;
+            }
+          }
+          if (__builtin_amdgcn_ballot_w64(unsafe) == 0ull) return;
+        }
+        todo[g] |= 1ull << t;
       };
 
       // the planes of the next added row are in flight while up to four paths are tested against the current one
@@ -498,7 +543,6 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
         u32 m = (blo | bhi) & valid;
         if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) return;
         n_slow++;
-        dirty = true;
         const u32 diag = sp_diag_offset(it.tot);
         while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {   // one permutation per lane and round
           if (lq_n + 64u > kLqCap) lq_drain();
