@@ -660,15 +660,21 @@ class ResidentPlan:
         for name in ("2", "3"):
             if name in self.uids:
                 self.uids[name].set_reduced(parsed1, lv.data_inds["3"])
+        self._reduced_args: Dict[str, tuple] = {}
+        self._pivot: Dict[tuple, DeviceUids] = {}
+        # off by default: measured -- the level-4 shard gains 3 %, keeping all of level 2's planes costs more
+        self.pivot_shards = os.environ.get("GCRE_PIVOT_SHARDS", "0") == "1"
         if "4" in self.uids:    # level 2 put the added gene into the (-) half of paths2[loc] when the relation is negative
-            self.uids["4"].set_reduced(parsed1, np.asarray(lv.data_inds["3"], np.int64) | (rel_neg.astype(np.int64) << 31))
+            self._reduced_args["4"] = (parsed1, np.asarray(lv.data_inds["3"], np.int64) | (rel_neg.astype(np.int64) << 31))
+            self.uids["4"].set_reduced(*self._reduced_args["4"])
         if "5" in self.uids:    # paths3[loc] = (c, d, e): the join adds paths2[(d, e)], swapped when (c, d) is negative
             u3 = lv.uids["3"]
             cnt = np.maximum(np.asarray(u3.count, dtype=np.int64), 0)
             start = np.repeat(np.asarray(u3.location, dtype=np.int64), cnt)
             within = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
             first_neg = np.repeat((np.asarray(u3.signs)[:len(cnt)] != 1) if signed else np.zeros(len(cnt), bool), cnt)
-            self.uids["5"].set_reduced(self.kept["2"], (start + within) | (first_neg.astype(np.int64) << 31))
+            self._reduced_args["5"] = (self.kept["2"], (start + within) | (first_neg.astype(np.int64) << 31))
+            self.uids["5"].set_reduced(*self._reduced_args["5"])
 
     def operands(self, name: str):
         """(paths0, paths1, paths_res) of one level, as in wrapper.cpp:227-276."""
@@ -692,6 +698,36 @@ class ResidentPlan:
         first = self._first[name]
         return (int(np.searchsorted(first, b, side="right")) - 1, int(np.searchsorted(first, e - 1, side="right")))
 
+    def pivot_sharded(self, name: str, world: int) -> bool:
+        """``GCRE_PIVOT_SHARDS=1``: levels that keep nothing (4 and 5) are sharded by PIVOT GROUP when there are several ranks:
+        all uids that join the same paths1 rows (same ``location``: the 3-paths ending in one gene) go to one rank, so the
+        planes of those rows are fetched on one GPU only.  The other levels keep an ordinal range (their kept rows must be
+        ranges).  Exact like any sharding; not the default because it does not pay."""
+        return self.pivot_shards and world > 1 and name in ("4", "5") and name in self.uids
+
+    def pivot_uids(self, name: str, rank: int, world: int) -> DeviceUids:
+        """The join index of level ``name`` with ``count = 0`` outside this rank's pivot groups (the reference skips such
+        uids, src/join_base.cpp:236): a shard by uid subset that needs nothing below the C ABI.  Groups are cut at equal
+        cumulative path counts; a rank's joined paths stay in the level's order, so ties are cut as on one GPU."""
+        key = (name, rank, world)
+        if key not in self._pivot:
+            u = self.problem.levels.uids[name]
+            cnt = np.maximum(np.asarray(u.count, dtype=np.int64), 0)
+            loc = np.asarray(u.location, dtype=np.int64)
+            groups, inv = np.unique(np.where(cnt > 0, loc, -1), return_inverse=True)
+            weight = np.bincount(inv, weights=cnt.astype(np.float64), minlength=len(groups))
+            cum = np.concatenate([[0.0], np.cumsum(weight)])
+            total = cum[-1]
+            g_lo = int(np.searchsorted(cum, total * rank / world, side="left"))
+            g_hi = int(np.searchsorted(cum, total * (rank + 1) / world, side="left")) if rank + 1 < world else len(groups)
+            mine = (inv >= g_lo) & (inv < g_hi)
+            from .uids import UidRelSet
+            sub = UidRelSet(u.path_length, u.src, u.trg, np.where(mine, cnt, 0).astype(np.int32), u.location, u.signs)
+            du = DeviceUids(self.ex, sub)
+            du.set_reduced(*self._reduced_args[name])
+            self._pivot[key] = du
+        return self._pivot[key]
+
     def needed_rows(self, name: str, rank: int, world: int) -> Optional[Tuple[int, int]]:
         """What THIS rank needs of the set level ``name`` keeps, as a range of its rows (None: everything).
         Level 3's rows are only read as paths0 of the level-4 shard: the others are not produced at all
@@ -700,6 +736,10 @@ class ResidentPlan:
         as paths0 (keep_ranged = 2, see ``keep_mode``).  With level 5 in the run every rank needs all of levels 2
         and 3 (level 5 joins level 3 with itself through level 2's planes)."""
         if world == 1 or "5" in self.uids or name not in ("1a", "2", "3"):
+            return None
+        if self.pivot_sharded("4", world) and name in ("2", "3"):
+            # a rank's pivot groups read level-3 rows from everywhere, and their recipes start at arbitrary rows of level 2:
+            # every rank keeps all of both (level 3 as recipes, level 2 with its planes)
             return None
         key = (name, rank, world)
         if key in self._needed:
@@ -780,7 +820,9 @@ class ResidentPlan:
                 p0, p1, res = self.operands(name)
                 b, e = self.shard(name, rank, world)
                 n_ex = self.exchange_count(name, world) if (exchange is not None and d_null_out) else 0
-                r = self.ex.join(self.uids[name], p0, p1, res, shard=(b, e) if world > 1 else None,
+                by_pivot = self.pivot_sharded(name, world)
+                r = self.ex.join(self.pivot_uids(name, rank, world) if by_pivot else self.uids[name], p0, p1, res,
+                                 shard=(b, e) if (world > 1 and not by_pivot) else None,
                                  d_null_out=(d_null_out + 4 * k0) if d_null_out else 0,
                                  keep=self.needed_rows(name, rank, world), keep_mode=self.keep_mode(name),
                                  exchange=(lambda a, b_, name=name: exchange(name, a, b_)) if n_ex else None, exchanges=n_ex)

@@ -222,7 +222,7 @@ struct gcre_ctx {
   int ieq_batch = 0;                 // GCRE_IEQ_BATCH: quads per ticket of the quad kernel (0: twice ie_batch)
   int ie_quad = 1;                   // GCRE_IE_QUAD=0: the pruned method-1 launches stay on k_null_ie_m1 (cross-check)
   int ie_warm_items = 4;             // (segment, tile) items per wave of the warm-up launch (GCRE_IE_WARM_ITEMS)
-  int ie_warm_segs = 2048;           // least number of segments in the warm-up slice (GCRE_IE_WARM)
+  int ie_warm_segs = 1024;           // least number of segments in the warm-up slice (GCRE_IE_WARM; 2048 until round 3: the filter's second look made early thresholds matter less)
   int ie_small_join_tiles = 8;       // GCRE_IE_SJT (tuning)
   int ie_batch = 2;                  // segments per ticket (GCRE_IE_BATCH)
   uint32_t* d_queue = nullptr;       // ticket counters of the pruned kernels' work queues (8 x 16 words)

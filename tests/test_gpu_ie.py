@@ -256,6 +256,38 @@ def test_ranks_only_keep_the_rows_they_need(world, monkeypatch):
         np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
 
 
+@pytest.mark.parametrize("method,L", [("method1", 4), ("method1", 5), ("method2", 4)])
+@pytest.mark.parametrize("world", [2, 5])
+def test_pivot_group_shards_reproduce_the_full_join(method, L, world, monkeypatch):
+    """GCRE_PIVOT_SHARDS=1: the last levels sharded by pivot group -- a join index with count = 0 outside the rank's groups
+    (the reference skips such uids, src/join_base.cpp:236) -- instead of by ordinal range.  Every uid is scored by exactly
+    one rank, the merged results equal the oracle's, ids included (a rank's paths stay in the level's order)."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_PIVOT_SHARDS", "1")
+    p = sparse_problem(method, 12, K=120, L=L)
+    want = oracle.process_paths(p, order="canonical")
+    parts, covered = [], {}
+    for rank in range(world):
+        plan = api.ResidentPlan(p)
+        assert plan.pivot_sharded(str(L), world) and plan.needed_rows("3", rank, world) is None
+        parts.append(plan.run(rank=rank, world=world))
+        for name in ("4", "5")[: L - 3]:
+            covered[name] = covered.get(name, 0) + plan.pivot_uids(name, rank, world).total_paths
+        plan.close()
+    for name, total in covered.items():
+        assert total == int(np.maximum(np.asarray(p.levels.uids[name].count), 0).sum())
+    for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4), ("5", 5))[:L]:
+        null = np.maximum.reduce([r[name].null for r in parts])
+        rows = [np.stack([r[name].scores, r[name].src, r[name].trg, r[name].cases, r[name].ctrls], axis=1) for r in parts]
+        best = dist.merge_topk(np.vstack(rows), p.top_k)
+        w = want[f"lst{lvl}"]
+        np.testing.assert_array_equal(null.view(np.uint32), w.null.view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(best[:, 0], w.scores, err_msg=name)
+        distinct = np.r_[True, w.scores[1:] != w.scores[:-1]] & np.r_[w.scores[1:] != w.scores[:-1], True]
+        np.testing.assert_array_equal(best[distinct, 1].astype(np.int64), w.src[distinct], err_msg=name)
+        np.testing.assert_array_equal(best[distinct, 2].astype(np.int64), w.trg[distinct], err_msg=name)
+
+
 @pytest.mark.parametrize("method", ["method1", "method2"])
 @pytest.mark.parametrize("tiles", ["1", "2"])
 def test_permutation_windows_change_nothing(method, tiles, monkeypatch):
