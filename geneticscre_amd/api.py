@@ -778,7 +778,8 @@ class ResidentPlan:
         work = self.uids[name].total_paths / world * tiles
         if unit <= 0 or work < 2 * unit:
             return 0
-        return int(min(8, np.floor(np.log2(work / unit))))
+        most = min(max(float(os.environ.get("GCRE_EXCHANGE_MAX", 8)), 1.0), 32.0)
+        return int(min(most, np.floor(np.log2(work / unit))))
 
     def run(self, rank: int = 0, world: int = 1, d_null_out: int = 0, on_level=None,
             keep_inspections: bool = False, exchange=None) -> Dict[str, JoinResult]:

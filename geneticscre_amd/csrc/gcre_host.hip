@@ -222,6 +222,7 @@ struct gcre_ctx {
   int ieq_batch = 0;                 // GCRE_IEQ_BATCH: quads per ticket of the quad kernel (0: twice ie_batch)
   int ie_quad = 1;                   // GCRE_IE_QUAD=0: the pruned method-1 launches stay on k_null_ie_m1 (cross-check)
   int ie_warm_items = 4;             // (segment, tile) items per wave of the warm-up launch (GCRE_IE_WARM_ITEMS)
+  int exchange_tail = 0;             // slices of the pruned launch that are equal steps at its end (GCRE_EXCHANGE_TAIL; -1: half of them; 0: doubling slices only)
   int ie_warm_segs = 1024;           // least number of segments in the warm-up slice (GCRE_IE_WARM; 2048 until round 3: the filter's second look made early thresholds matter less)
   int ie_small_join_tiles = 8;       // GCRE_IE_SJT (tuning)
   int ie_batch = 2;                  // segments per ticket (GCRE_IE_BATCH)
@@ -1812,15 +1813,21 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             // tickets are 32-bit: (batches per tile) x tiles must stay below 2^32
             while (((ia.nsegs - ia.seg_begin) / ia.batch + 1) * (int64_t)ia.nkt > (int64_t)0xf0000000ll) ia.batch *= 2;
             // One launch -- or, when the maxima are shared with other devices as the join goes (gcre_join_opts.exchange),
-            // E slices 1/2^(E-1), .., 1/4, 1/2 of the range with an exchange before each: the thresholds of a shard then
-            // follow the whole level's maxima (the maximum over n paths grows like log n: early exchanges matter most).
+            // E slices with an exchange before each, so that the thresholds of a shard follow the whole level's maxima: the
+            // first slices double (1/2^k of the head), the last m = exchange_tail are equal steps 1/(m+1) of the range.
+            // Measured at 8 ranks on configs[3]: equal steps at the end and up to 16 exchanges halve the
+            // look-ups once more but every slice is a launch that starts cold -- doubling slices alone (m = 0) stay best.
             const bool pruned = c->d_ladder && ia.lad_mode == 0;
             const int n_slices = (pruned && jp.exchange) ? std::max(1, jp.exchanges - exchanges_done) : 1;
             const int64_t r_b = quad ? ia.quad_begin : ia.seg_begin, r_e = quad ? ia.quad_end : ia.seg_end;
             int64_t lo = r_b;
             for (int sl = 0; sl < n_slices && lo < r_e; sl++) {
               int64_t hi = r_e;
-              if (sl + 1 < n_slices) hi = std::min(r_e, std::max(lo + 1, r_b + ((r_e - r_b) >> (n_slices - 1 - sl))));
+              if (sl + 1 < n_slices) {
+                const int m = std::min(n_slices - 1, c->exchange_tail < 0 ? n_slices / 2 : c->exchange_tail), head = n_slices - m;
+                const double end = sl >= head ? (double)(sl - head + 2) / (double)(m + 1) : std::ldexp(1.0 / (double)(m + 1), -(head - 1 - sl));
+                hi = std::min(r_e, std::max(lo + 1, r_b + (int64_t)((double)(r_e - r_b) * end)));
+              }
               if (pruned && jp.exchange)
                 if (int rc = exchange_now()) return rc;
               IeArgs sa2 = ia;
@@ -2185,6 +2192,7 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   if (const char* e = std::getenv("GCRE_NULL_KERNEL"))
     c->null_kernel = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "sparse") ? 2 : !std::strcmp(e, "ie") ? 3 : 0;
   if (const char* e = std::getenv("GCRE_IE_PRUNE")) c->ie_prune = std::atoi(e) != 0;
+  if (const char* e = std::getenv("GCRE_EXCHANGE_TAIL")) c->exchange_tail = std::min(std::max(std::atoi(e), -1), 64);
   if (const char* e = std::getenv("GCRE_IE_WARM")) c->ie_warm_segs = std::min(std::max(std::atoi(e), 0), 1 << 20);
   if (const char* e = std::getenv("GCRE_IE_WARM_ITEMS")) c->ie_warm_items = std::min(std::max(std::atoi(e), 1), 64);
   if (const char* e = std::getenv("GCRE_IE_SJT")) c->ie_small_join_tiles = std::atoi(e);
@@ -2786,7 +2794,9 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
           // fails the call (its thread then fails the hub) instead of silently joining with none -- the others would wait
           // for it for ever, or pair their round with its next join
           if (c->d_hub_null.reserve((size_t)c->g.Kpad + 64) != hipSuccess) return fail(c, GCRE_ERR_DEVICE, "no memory for the exchange buffer");
-          jp.exchanges = (int)std::min(8.0, std::floor(std::log2(work / unit)));
+          double most = 8.0;
+          if (const char* e = std::getenv("GCRE_EXCHANGE_MAX")) most = std::min(std::max(std::atof(e), 1.0), 32.0);
+          jp.exchanges = (int)std::min(most, std::floor(std::log2(work / unit)));
           jp.d_null_out = c->d_hub_null.p;
           jp.exchange_user = c;
           c->hub_level = lvi;          // 0..5 = levels 1a, 1b, 2, 3, 4, 5
