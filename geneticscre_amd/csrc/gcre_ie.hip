@@ -1886,9 +1886,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3
   constexpr u32 kOverChunk = 2048;
   __shared__ u32 slot_lds[4][64 * 8];   // the 64 paths' list slots
   __shared__ u32 out_lds[4][8][64];     // their result words: tot, cases, ctrls, rowz, key lo, key hi, linfo, lover
+  __shared__ u32 pair_lds[4][4][3][32 * NL];   // per group: the non-zero words of the current path's list (low, high, word index)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sl = lane & 15, grp = lane >> 4;
+  const u32 gsh = (u32)grp * 16u, ltm = (1u << sl) - 1u;
+  u32 (*pairs)[32 * NL] = pair_lds[wv][grp];
   const i64 wave = (i64)blockIdx.x * 4 + wv;
   const i64 nwaves = (i64)gridDim.x * 4;
   const int Wp = a.Wp;
@@ -2015,28 +2018,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3
       }
       const bool ov_ok = active && len8 > 8u && (u64)ovb + (len8 - 8u) <= (u64)a.over_cap;
       u32* over = a.over + ovb;
-      u32 mine = 0u;
-#pragma unroll
-      for (int it = 0; it < NL; it++)
-#pragma unroll
-        for (int e = 0; e < 2; e++) mine += (u32)__popcll(mode ? (zw[it][e] & xw[it][e]) : (zw[it][e] & ~xw[it][e]));
-      u32 pos = row_scan_add(mine) - mine;
+      // The list's bits are few and scattered -- three overlapping patients among a path's 96 lane-words -- so a loop per
+      // word runs its body for one lane at a time.  Instead the non-zero words are first collected per group (word, its
+      // index; positions from a ballot), then every lane takes one collected word and all of them give up a bit per round:
+      // two rounds instead of eight bodies.  Entries come out in collection order, not ascending (the list is a set).
+      u32 npair = 0u;
 #pragma unroll
       for (int it = 0; it < NL; it++) {
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-          u64 w = mode ? (zw[it][e] & xw[it][e]) : (zw[it][e] & ~xw[it][e]);
-          const u32 k = (u32)(it * 32 + 2 * sl + e);
-          while (w) {
-            const u32 b = (u32)__builtin_ctzll(w);
-            w &= w - 1;
+          const u64 w = mode ? (zw[it][e] & xw[it][e]) : (zw[it][e] & ~xw[it][e]);
+          const bool nz = active && w != 0;
+          const u64 bal = __builtin_amdgcn_ballot_w64(nz);
+          if (bal == 0ull) continue;
+          const u32 m = (u32)(bal >> gsh) & 0xffffu;
+          const u32 at = npair + (u32)__builtin_popcount(m & ltm);
+          if (nz) {
+            pairs[0][at] = (u32)w;
+            pairs[1][at] = (u32)(w >> 32);
+            pairs[2][at] = (u32)(it * 32 + 2 * sl + e);
+          }
+          npair += (u32)__builtin_popcount(m);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        const u32 npmax = max(max(rdlane(npair, 0), rdlane(npair, 16)), max(rdlane(npair, 32), rdlane(npair, 48)));
+        u32 cnt = 0u;
+        for (u32 p0 = 0u; p0 < npmax; p0 += 16u) {
+          const u32 pi = p0 + (u32)sl;
+          const bool has = pi < npair;
+          u64 w = has ? ((u64)pairs[1][pi] << 32) | (u64)pairs[0][pi] : 0ull;
+          const u32 k = has ? pairs[2][pi] : 0u;
+          while (__builtin_amdgcn_ballot_w64(w != 0ull) != 0ull) {
+            const bool nzb = w != 0ull;
+            const u32 m = (u32)(__builtin_amdgcn_ballot_w64(nzb) >> gsh) & 0xffffu;
+            const u32 pos = cnt + (u32)__builtin_popcount(m & ltm);
+            const u32 b = nzb ? (u32)__builtin_ctzll(w) : 0u;
+            w &= w - 1ull;
             const u32 en = (k * 64u + b) << 8;
-            if (pos < 8u) { if (active) slots[pl * 8 + (int)pos] = en; }
-            else if (ov_ok) over[pos - 8u] = en;
-            pos++;
+            if (nzb) {
+              if (pos < 8u) slots[pl * 8 + (int)pos] = en;
+              else if (ov_ok) over[pos - 8u] = en;
+            }
+            cnt += (u32)__builtin_popcount(m);
           }
         }
       }
+      __builtin_amdgcn_wave_barrier();
       for (u32 p = max(len, 8u) + (u32)sl; p < len8; p += 16)   // padding of the overflow part
         if (ov_ok) over[p - 8u] = a.zoff;
       // ---- the path's result words into LDS, lane pl of every array ----

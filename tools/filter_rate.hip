@@ -7,6 +7,7 @@
 //   2  masks already in vector registers (what the loop would cost if the bounds were free)
 //   3  variant 0 with the low two planes not compared (bounds rounded to multiples of 4)
 //   4  carry chain only: X + Y >= 0 for two pre-shifted operand pairs (no sums, no bounds)
+//   5  the packed bounds broadcast into a vector register, v_bfe_i32 per bit and bound, v_bitop3 with vector operands only
 // Diagnostic only.   hipcc --offload-arch=gfx950 -O3 tools/filter_rate.hip -o tools/filter_rate && tools/filter_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     };
     auto filter_f = [&](int g, u32 t, const u32 (&Bg)[L], const u32 (&Z)[LZ], const u32x16& mlo, const u32x16& mhi) {
       const u32 lf = rdlane(lfv[g], t);
+      u32 lfb = lf;
+      if (V == 5) asm volatile("v_mov_b32 %0, %1" : "=v"(lfb) : "s"(lf));   // a vector copy the compiler cannot fold back
       u32 cy = 0u, blo = 0u, bhi = 0u;
       if (V == 4) {
         // two carry chains (lower and upper test as sign tests of pre-shifted sums): 2 x (L + 1) instructions
@@ -91,6 +94,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
           if (V == 0 || V == 3) {
             kl = (u32)__builtin_amdgcn_sbfe((int)lf, l, 1);
             kh = (u32)__builtin_amdgcn_sbfe((int)lf, 16 + l, 1);
+          } else if (V == 5) {
+            kl = (u32)__builtin_amdgcn_sbfe((int)lfb, l, 1);
+            kh = (u32)__builtin_amdgcn_sbfe((int)lfb, 16 + l, 1);
           } else if (V == 1) {
             kl = mlo[l]; kh = mhi[l];
           } else {
@@ -181,6 +187,8 @@ int main() {
   if (run<2, 3>("masks in VGPRs (bound free)", 3)) return 1;
   if (run<3, 3>("sbfe, low 2 planes skipped", 3)) return 1;
   if (run<3, 4>("sbfe, low 2 planes skipped", 4)) return 1;
+  if (run<5, 3>("v_bfe on a vector copy", 3)) return 1;
+  if (run<5, 4>("v_bfe on a vector copy", 4)) return 1;
   if (run<4, 3>("two carry chains only", 3)) return 1;
   if (run<4, 4>("two carry chains only", 4)) return 1;
   return 0;
