@@ -96,6 +96,26 @@ def test_shared_thresholds_with_windows_and_quads(monkeypatch):
             assert calls[(rank, "4", k0)] == counts["4"]
 
 
+@pytest.mark.parametrize("tail", ["-1", "3", "40"])
+def test_exchange_schedules_change_no_result(tail, monkeypatch):
+    """GCRE_EXCHANGE_TAIL / GCRE_EXCHANGE_MAX only move the points at which a join hands its maxima over (the last slices
+    equal steps instead of doubling ones, up to 12 of them): same calls as announced, same merged results."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_EXCHANGE_UNIT", "2")
+    monkeypatch.setenv("GCRE_EXCHANGE_MAX", "12")
+    monkeypatch.setenv("GCRE_EXCHANGE_TAIL", tail)
+    monkeypatch.setenv("GCRE_IE_WARM", "64")
+    K = 2300
+    p = make_problem(60, 200, 310, 335, K, 4, method="method1", top_k=15, seed=35, threshold=0.05)
+    want = oracle.process_paths(p, order="canonical")
+    parts, calls, counts = run_ranks(p, 2, K)
+    check_merged(parts, want, p, 4)
+    assert max(counts.values()) >= 9
+    for rank in range(2):
+        for name, n in counts.items():
+            assert calls.get((rank, name, 0), 0) == n, (rank, name, calls, counts)
+
+
 def test_exchange_is_ignored_without_a_device_buffer():
     """No d_null_out: nothing to hand over -- the join runs as if no exchange had been asked for."""
     p = make_problem(40, 110, 100, 120, 300, 3, method="method1", top_k=10, seed=33)
