@@ -1879,8 +1879,11 @@ hipError_t launch_range_union(const uint64_t* p1, const uint64_t* pz, const int3
 // rows are read 16 bytes per lane.  Sixteen lanes per path, four paths at a time, as before.
 // NL = 16-byte loads per row and lane = ceil(Wp / 32) (Wp <= 32 * NL).
 // ------------------------------------------------------------------------------------------------
+#ifndef GCRE_STATS_WAVES
+#define GCRE_STATS_WAVES 4   // 10 spilled registers at four waves per SIMD, and still faster than three (6.26 against 6.72 ms per pass)
+#endif
 template <int NL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3 : 2))) void k_stats_ie2(const StatsArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? GCRE_STATS_WAVES : 2))) void k_stats_ie2(const StatsArgs a) {
   typedef u64 __attribute__((ext_vector_type(2))) u64x2;
   constexpr u32 kNoRange = 0xffffffffu;
   constexpr u32 kOverChunk = 2048;
@@ -1892,6 +1895,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3
   const int sl = lane & 15, grp = lane >> 4;
   const u32 gsh = (u32)grp * 16u, ltm = (1u << sl) - 1u;
   u32 (*pairs)[32 * NL] = pair_lds[wv][grp];
+  __shared__ u32 meta_lds[4][3][64];    // the 64 paths' paths0 row, reduced row, range
+  u32 (*meta)[64] = meta_lds[wv];
   const i64 wave = (i64)blockIdx.x * 4 + wv;
   const i64 nwaves = (i64)gridDim.x * 4;
   const int Wp = a.Wp;
@@ -1901,13 +1906,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3
   bool my_bad = false;
   u32 chunk_at = 0u, chunk_left = 0u;
   // this lane's words of a row: 2 sl, 2 sl + 1 of every 32-word block
-  u64 cmw[NL][2];
-#pragma unroll
-  for (int it = 0; it < NL; it++) {
-    const int k = it * 32 + 2 * sl;
-    cmw[it][0] = k < Wp ? a.case_mask[k] : 0;
-    cmw[it][1] = k + 1 < Wp ? a.case_mask[k + 1] : 0;
-  }
+  // the case mask sits in LDS (words beyond Wp zero), read where it is used: twelve registers less per lane
+  __shared__ u64 cm_lds[32 * NL];
+  for (int k = (int)threadIdx.x; k < 32 * NL; k += 256) cm_lds[k] = k < Wp ? a.case_mask[k] : 0;
+  __syncthreads();
   const i64 nblocks = (a.count + 63) / 64;
   for (i64 blk = wave; blk < nblocks; blk += nwaves) {
     const i64 base = blk * 64;
@@ -1918,6 +1920,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3
     const u32 zv = a.zindex ? (u32)a.zindex[r1v & 0x7fffffffu] : (r1v & 0x7fffffffu);
     u32 rngv = kNoRange;   // the uid's row of the excess table, for the first path of a uid in this launch only
     if (a.excess && (iq == 0 || a.row0[iq - 1] != r0v)) rngv = (u32)a.range_of[r0v];
+    // (lane t <-> path t: parked in LDS, read back per group -- three registers less than keeping them for ds_bpermute)
+    meta[0][lane] = r0v;
+    meta[1][lane] = zv & 0x7fffffffu;
+    meta[2][lane] = rngv;
+    __builtin_amdgcn_wave_barrier();
     // slots start as padding
     {
       const u32x4 pad = {a.zoff, a.zoff, a.zoff, a.zoff};
@@ -1937,9 +1944,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3
     u32 n_rz = 0u, n_rng = kNoRange, n_r0 = 0xffffffffu;
     auto fetch_rows = [&](int it4n) {
       const int pln = it4n * 4 + grp;
-      const u32 r0n = (u32)__builtin_amdgcn_ds_bpermute(pln << 2, (int)r0v);
-      n_rz = (u32)__builtin_amdgcn_ds_bpermute(pln << 2, (int)zv) & 0x7fffffffu;
-      n_rng = (u32)__builtin_amdgcn_ds_bpermute(pln << 2, (int)rngv);
+      const u32 r0n = meta[0][pln];
+      n_rz = meta[1][pln];
+      n_rng = meta[2][pln];
       const bool new_x = r0n != n_r0;
       n_r0 = r0n;
       const u64* xn = a.p0 + (size_t)r0n * a.S;
@@ -1975,12 +1982,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3
         const int k = it * 32 + 2 * sl;
         u64x2 uv = {0, 0};
         if (k < Wp && uu) uv = *(const u64x2*)(uu + k);
+        const u64x2 cmv = *(const u64x2*)(cm_lds + k);
+        const u64 cme[2] = {cmv.x, cmv.y};
 #pragma unroll
         for (int e = 0; e < 2; e++) {
           const u64 xk = xw[it][e], zk = zw[it][e], uk = e ? uv.y : uv.x;
           stray |= uk & ~xk;
           const u64 j = xk | zk;
-          cc += (u32)__popcll(j & cmw[it][e]) | ((u32)__popcll(j) << 16);
+          cc += (u32)__popcll(j & cme[e]) | ((u32)__popcll(j) << 16);
           dv += (u32)__popcll(zk & ~xk) | ((u32)__popcll(zk) << 16);
         }
         if (out && k < Wp) *(u64x2*)(out + k) = u64x2{xw[it][0] | zw[it][0], xw[it][1] | zw[it][1]};
