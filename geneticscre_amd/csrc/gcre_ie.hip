@@ -1935,12 +1935,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? G
     // so that the wave never sits on that load
     double score_prev = 0.0;
     int pl_prev = -1;
-    // the rows of the next four paths are requested while these four are worked on
+    // The rows of the next four paths are requested as soon as these four have given up their list words (behind the
+    // collection pass below), straight into the registers the current rows occupied: one set of row registers instead of
+    // two is what lets a fourth wave onto the SIMD, and the other waves cover what the shorter distance no longer does.
     // (consecutive joined paths mostly share their paths0 row -- one uid joins ~11 rows at level 4: a group that stays
     // on the same row keeps its words, and when no group moves on the load is not issued at all)
-    u64x2 nx[NL], nz[NL];
+    u64 xw[NL][2], zw[NL][2];
 #pragma unroll
-    for (int it = 0; it < NL; it++) nx[it] = nz[it] = u64x2{0, 0};
+    for (int it = 0; it < NL; it++) xw[it][0] = xw[it][1] = zw[it][0] = zw[it][1] = 0ull;
     u32 n_rz = 0u, n_rng = kNoRange, n_r0 = 0xffffffffu;
     auto fetch_rows = [&](int it4n) {
       const int pln = it4n * 4 + grp;
@@ -1955,8 +1957,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? G
       for (int it = 0; it < NL; it++) {
         const int k = it * 32 + 2 * sl;
         if (k < Wp) {            // Wp is a multiple of 4: words k and k + 1 are both inside
-          if (new_x) nx[it] = *(const u64x2*)(xn + k);
-          nz[it] = *(const u64x2*)(zn + k);
+          if (new_x) {
+            const u64x2 v = *(const u64x2*)(xn + k);
+            xw[it][0] = v.x; xw[it][1] = v.y;
+          }
+          const u64x2 v = *(const u64x2*)(zn + k);
+          zw[it][0] = v.x; zw[it][1] = v.y;
         }
       }
     };
@@ -1968,13 +1974,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? G
       const u32 rz = n_rz, rng = n_rng;
       const u64* uu = (rng != kNoRange) ? a.excess + (size_t)rng * a.S : nullptr;
       u64* out = (a.res && active) ? a.res + (size_t)(a.first + base + pl) * a.S : nullptr;
-      u64 xw[NL][2], zw[NL][2];
-#pragma unroll
-      for (int it = 0; it < NL; it++) {
-        xw[it][0] = nx[it].x; xw[it][1] = nx[it].y;
-        zw[it][0] = nz[it].x; zw[it][1] = nz[it].y;
-      }
-      fetch_rows(it4 < 15 ? it4 + 1 : 15);
       u32 cc = 0u, dv = 0u;
       u64 stray = 0;
 #pragma unroll
@@ -2050,6 +2049,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? G
           npair += (u32)__builtin_popcount(m);
         }
       }
+      fetch_rows(it4 < 15 ? it4 + 1 : 15);   // (changes rz / rng of the NEXT iteration only: this one read them above)
       __builtin_amdgcn_wave_barrier();
       {
         const u32 npmax = max(max(rdlane(npair, 0), rdlane(npair, 16)), max(rdlane(npair, 32), rdlane(npair, 48)));
