@@ -1,0 +1,62 @@
+"""Seeded random problems through the C ABI against the CPU oracle, bit-exact: sizes, carrier thresholds, permutation
+counts, methods, path lengths, kernel forms and tuning knobs drawn per case (pytest -m gpu).  A handful of cases by
+default; GCRE_FUZZ_CASES=200 for a long run after a kernel change (the draw only depends on the case number)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from geneticscre_amd import api
+from geneticscre_amd.synth import make_problem
+from helpers import assert_same_result
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = int(os.environ.get("GCRE_FUZZ_CASES", "8"))
+KNOBS = {
+    "GCRE_NULL_KERNEL": ["", "ie", "ie", "ie", "sparse", "dense"],
+    "GCRE_IE_QUAD": ["", "0", "2", "2"],
+    "GCRE_IE_WARM": ["", "0", "64", "256"],
+    "GCRE_IE_PRUNE": ["", "", "", "0"],
+    "GCRE_IEQ_BATCH": ["", "1", "3"],
+    "GCRE_IE_BATCH": ["", "1", "5"],
+    "GCRE_WINDOW_TILES": ["", "", "1", "2"],
+    "GCRE_PLANES_OUT_MAX_MB": ["", "", "0"],
+}
+
+
+def draw(case: int):
+    rng = np.random.default_rng(9000 + case)
+    n_cases = int(rng.integers(20, 420))
+    n_ctrls = int(rng.integers(20, 420))
+    genes = int(rng.integers(25, 90))
+    edges = int(rng.integers(genes * 2, genes * 5))
+    length = int(rng.choice([3, 4, 4, 5]))
+    if case % 5 == 4:      # a larger network: thousands of segments per join, quads, several chunks of work per wave
+        genes = int(rng.integers(150, 320))
+        edges = int(rng.integers(genes * 3, genes * 6))
+        length = int(rng.choice([3, 4, 4]))
+    if length == 5:
+        edges = min(edges, genes * 3)
+    perms = int(rng.choice([0, 1, 31, 100, 257, 2048, 2300, 4500]))
+    method = str(rng.choice(["method1", "method1", "method2"]))
+    threshold = float(rng.choice([0.02, 0.05, 0.05, 0.15, 0.4]))
+    top_k = int(rng.choice([1, 7, 15, 40]))
+    env = {k: str(rng.choice(v)) for k, v in KNOBS.items()}
+    return dict(n_cases=n_cases, n_ctrls=n_ctrls, genes=genes, edges=edges, length=length, perms=perms, method=method,
+                threshold=threshold, top_k=top_k, seed=1000 + case), env
+
+
+@pytest.mark.parametrize("case", range(N_CASES))
+def test_random_problem_matches_oracle(case, monkeypatch):
+    cfg, env = draw(case)
+    for k, v in env.items():
+        if v:
+            monkeypatch.setenv(k, v)
+    p = make_problem(cfg["genes"], cfg["edges"], cfg["n_cases"], cfg["n_ctrls"], cfg["perms"], cfg["length"],
+                     method=cfg["method"], top_k=cfg["top_k"], seed=cfg["seed"], threshold=cfg["threshold"])
+    want = oracle.process_paths(p, order="canonical")
+    got = api.process_paths(p)
+    for lvl in range(1, cfg["length"] + 1):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
