@@ -10,6 +10,7 @@ import oracle
 from geneticscre_amd import api
 from geneticscre_amd.synth import make_problem
 from helpers import assert_same_result
+from test_gpu_exchange import check_merged, run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -60,3 +61,21 @@ def test_random_problem_matches_oracle(case, monkeypatch):
     got = api.process_paths(p)
     for lvl in range(1, cfg["length"] + 1):
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+
+
+@pytest.mark.parametrize("case", range(max(1, N_CASES // 4)))
+def test_random_sharded_plan_matches_oracle(case, monkeypatch):
+    """The same draw through ResidentPlan, sharded over 2..5 ranks with the thresholds exchanged inside the joins: the
+    merged null maxima and top-k are the oracle's."""
+    cfg, env = draw(100000 + case)
+    env["GCRE_WINDOW_TILES"] = ""
+    env["GCRE_EXCHANGE_UNIT"] = str([5, 50, 2000][case % 3])
+    for k, v in env.items():
+        if v:
+            monkeypatch.setenv(k, v)
+    K = max(cfg["perms"], 1)
+    p = make_problem(cfg["genes"], cfg["edges"], cfg["n_cases"], cfg["n_ctrls"], K, min(cfg["length"], 4),
+                     method=cfg["method"], top_k=cfg["top_k"], seed=cfg["seed"], threshold=cfg["threshold"])
+    want = oracle.process_paths(p, order="canonical")
+    parts, _, _ = run_ranks(p, 2 + case % 4, K)
+    check_merged(parts, want, p, min(cfg["length"], 4))
