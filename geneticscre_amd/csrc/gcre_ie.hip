@@ -769,7 +769,9 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
             bhi = borrow3(kh, W[l], bhi);    // W > hi
           }
           if ((lo2 >> L) != 0u) blo = 0xffffffffu;   // the margin pushed the bound past the counters' range
-          mu = (blo | bhi) & valid;
+          // W = N0 + Nz can pass 2^L although no count of the path does (the planes are sized for the largest carrier total
+          // of the joined paths, and W counts the overlap twice): a carry out of the top plane is "above hi", not a small W
+          mu = (blo | bhi | cy) & valid;
         } else {
 #pragma unroll
           for (int l = 0; l < L; l++) W[l] = B[l];

@@ -389,7 +389,9 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
           blo = borrow3(w, kl, blo);    // W < lo + ov
           bhi = borrow3(kh, w, bhi);    // W > hi
         }
-        u32 fm = (blo | bhi) & valid;
+        // (W counts the overlap twice and can pass 2^L although no count of the path does: a carry out of the top plane is
+        // "above hi", not a small W)
+        u32 fm = (blo | bhi | cy) & valid;
         if (__builtin_amdgcn_ballot_w64(fm != 0u) == 0ull) return;
         // ---- a second look, permutation by permutation.  The interval above belongs to the LOWEST running maximum of the
         // tile's 2048 permutations; a flagged permutation only matters if its count can leave the (wider) interval of its
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
           const u32 ov = (info & kLinfoLenMask) - (info >> 28);
           const u32* lad_t = a.ladder + rdlane(totv[g], t);
           u32 Wp[L];
+          u32 c2 = 0u;
           {
-            u32 c2 = 0u;
 #pragma unroll
             for (int l = 0; l < L; l++) {
               if (l < LZ) {
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
             const bool has = fm != 0u;
             const u32 bb = has ? (u32)__builtin_ctz(fm) : 0u;
             fm &= fm - 1u;
-            u32 cnt = 0u;
+            u32 cnt = ((c2 >> bb) & 1u) << L;   // the carry out of the top plane is part of W
 #pragma unroll
             for (int l = 0; l < L; l++) cnt |= ((Wp[l] >> bb) & 1u) << l;
             if (has) {

@@ -475,3 +475,17 @@ def test_inspector_row_widths_up_to_160_words(patients, monkeypatch):
         np.testing.assert_array_equal(plan.kept["2"].to_numpy(), want["paths2"])
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize("quad", ["0", "2"])
+def test_bound_sum_past_the_counter_planes_is_not_inside(quad, monkeypatch):
+    """The bound filter adds the base counts and the added row's counts, overlap counted twice: with dense rows that sum
+    passes 2^L although no count of the joined path does (250 + 45 patients, carriers up to 40 %: 9 counter planes, sums up
+    to 590).  The carry out of the top plane means "above hi"; dropped, the wrapped sum looked inside the interval and two
+    null maxima of a level came out too low (found by tests/test_gpu_fuzz.py, case 5328)."""
+    monkeypatch.setenv("GCRE_NULL_KERNEL", "ie")
+    monkeypatch.setenv("GCRE_IE_QUAD", quad)
+    monkeypatch.setenv("GCRE_IE_WARM", "256")
+    p = make_problem(80, 240, 250, 45, 257, 5, method="method1", top_k=40, seed=6328, threshold=0.4)
+    want = oracle.process_paths(p, order="canonical")
+    check_levels(api.process_paths(p), want, range(1, 6))
