@@ -27,10 +27,31 @@ KNOBS = {
 }
 
 
+def value_table(kind: str, n_cases: int, n_ctrls: int, seed: int):
+    """None = the hypergeometric table; otherwise an arbitrary one (the pruning must be exact for any table)."""
+    if kind == "hyper":
+        return None
+    rng = np.random.default_rng(seed)
+    t = rng.random((n_cases + 1, n_ctrls + 1)) * 12.0
+    if kind == "ties":
+        t = np.round(t)            # thirteen distinct values: ties everywhere
+    elif kind == "flat":
+        t[:] = 3.25
+        t[rng.integers(0, n_cases + 1, 40), rng.integers(0, n_ctrls + 1, 40)] = 9.5   # a few spikes
+    return t
+
+
 def draw(case: int):
     rng = np.random.default_rng(9000 + case)
     n_cases = int(rng.integers(20, 420))
     n_ctrls = int(rng.integers(20, 420))
+    if case % 7 == 3:      # lopsided cohorts, a handful of controls (or cases)
+        if rng.random() < 0.5:
+            n_ctrls = int(rng.integers(2, 12))
+        else:
+            n_cases = int(rng.integers(2, 12))
+    if case % 11 == 5:     # wider rows
+        n_cases, n_ctrls = int(rng.integers(400, 1100)), int(rng.integers(400, 1100))
     genes = int(rng.integers(25, 90))
     edges = int(rng.integers(genes * 2, genes * 5))
     length = int(rng.choice([3, 4, 4, 5]))
@@ -42,11 +63,12 @@ def draw(case: int):
         edges = min(edges, genes * 3)
     perms = int(rng.choice([0, 1, 31, 100, 257, 2048, 2300, 4500]))
     method = str(rng.choice(["method1", "method1", "method2"]))
-    threshold = float(rng.choice([0.02, 0.05, 0.05, 0.15, 0.4]))
-    top_k = int(rng.choice([1, 7, 15, 40]))
+    threshold = float(rng.choice([0.02, 0.05, 0.05, 0.15, 0.4, 0.9]))
+    top_k = int(rng.choice([1, 7, 15, 40, 3000]))
+    table = str(rng.choice(["hyper", "hyper", "random", "ties", "flat"]))
     env = {k: str(rng.choice(v)) for k, v in KNOBS.items()}
     return dict(n_cases=n_cases, n_ctrls=n_ctrls, genes=genes, edges=edges, length=length, perms=perms, method=method,
-                threshold=threshold, top_k=top_k, seed=1000 + case), env
+                threshold=threshold, top_k=top_k, seed=1000 + case, table=table), env
 
 
 @pytest.mark.parametrize("case", range(N_CASES))
@@ -56,7 +78,8 @@ def test_random_problem_matches_oracle(case, monkeypatch):
         if v:
             monkeypatch.setenv(k, v)
     p = make_problem(cfg["genes"], cfg["edges"], cfg["n_cases"], cfg["n_ctrls"], cfg["perms"], cfg["length"],
-                     method=cfg["method"], top_k=cfg["top_k"], seed=cfg["seed"], threshold=cfg["threshold"])
+                     method=cfg["method"], top_k=cfg["top_k"], seed=cfg["seed"], threshold=cfg["threshold"],
+                     table=value_table(cfg["table"], cfg["n_cases"], cfg["n_ctrls"], cfg["seed"]))
     want = oracle.process_paths(p, order="canonical")
     got = api.process_paths(p)
     for lvl in range(1, cfg["length"] + 1):
@@ -70,12 +93,42 @@ def test_random_sharded_plan_matches_oracle(case, monkeypatch):
     cfg, env = draw(100000 + case)
     env["GCRE_WINDOW_TILES"] = ""
     env["GCRE_EXCHANGE_UNIT"] = str([5, 50, 2000][case % 3])
+    env["GCRE_PIVOT_SHARDS"] = "1" if case % 2 else ""
     for k, v in env.items():
         if v:
             monkeypatch.setenv(k, v)
     K = max(cfg["perms"], 1)
     p = make_problem(cfg["genes"], cfg["edges"], cfg["n_cases"], cfg["n_ctrls"], K, min(cfg["length"], 4),
-                     method=cfg["method"], top_k=cfg["top_k"], seed=cfg["seed"], threshold=cfg["threshold"])
+                     method=cfg["method"], top_k=cfg["top_k"], seed=cfg["seed"], threshold=cfg["threshold"],
+                     table=value_table(cfg["table"], cfg["n_cases"], cfg["n_ctrls"], cfg["seed"]))
     want = oracle.process_paths(p, order="canonical")
     parts, _, _ = run_ranks(p, 2 + case % 4, K)
     check_merged(parts, want, p, min(cfg["length"], 4))
+
+
+@pytest.mark.parametrize("case", range(max(1, N_CASES // 4)))
+def test_random_resident_plan_with_kept_inspections(case, monkeypatch):
+    """ResidentPlan over the same draw: a pass, a pass that keeps its inspections, a pass that replays them under another
+    permutation window -- each the oracle's."""
+    cfg, env = draw(200000 + case)
+    env["GCRE_WINDOW_TILES"] = ""
+    for k, v in env.items():
+        if v:
+            monkeypatch.setenv(k, v)
+    K = max(cfg["perms"], 1)
+    L = min(cfg["length"], 4)
+    p = make_problem(cfg["genes"], cfg["edges"], cfg["n_cases"], cfg["n_ctrls"], K, L,
+                     method=cfg["method"], top_k=cfg["top_k"], seed=cfg["seed"], threshold=cfg["threshold"],
+                     table=value_table(cfg["table"], cfg["n_cases"], cfg["n_ctrls"], cfg["seed"]))
+    want = oracle.process_paths(p, order="canonical")
+    names = (("1b", 1), ("2", 2), ("3", 3), ("4", 4))[:L]
+    plan = api.ResidentPlan(p)
+    try:
+        for keep, window in ((False, None), (True, None), (True, 2048), (False, 2048)):
+            if window is not None:
+                plan.set_window(window)
+            got = plan.run(keep_inspections=keep)
+            for name, lvl in names:
+                assert_same_result(got[name], want[f"lst{lvl}"])
+    finally:
+        plan.close()
