@@ -1,6 +1,7 @@
 """Seeded random problems through the C ABI against the CPU oracle, bit-exact: sizes, carrier thresholds, permutation
 counts, methods, path lengths, kernel forms and tuning knobs drawn per case (pytest -m gpu).  A handful of cases by
-default; GCRE_FUZZ_CASES=200 for a long run after a kernel change (the draw only depends on the case number)."""
+default; GCRE_FUZZ_CASES=5000 [GCRE_FUZZ_BASE=1000000] for a long run after a kernel change (the draw only depends on the
+case number)."""
 import os
 
 import numpy as np
@@ -15,6 +16,7 @@ from test_gpu_exchange import check_merged, run_ranks
 pytestmark = pytest.mark.gpu
 
 N_CASES = int(os.environ.get("GCRE_FUZZ_CASES", "8"))
+BASE = int(os.environ.get("GCRE_FUZZ_BASE", "0"))      # another stretch of the case numbers
 KNOBS = {
     "GCRE_NULL_KERNEL": ["", "ie", "ie", "ie", "sparse", "dense"],
     "GCRE_IE_QUAD": ["", "0", "2", "2"],
@@ -73,7 +75,7 @@ def draw(case: int):
 
 @pytest.mark.parametrize("case", range(N_CASES))
 def test_random_problem_matches_oracle(case, monkeypatch):
-    cfg, env = draw(case)
+    cfg, env = draw(BASE + case)
     for k, v in env.items():
         if v:
             monkeypatch.setenv(k, v)
@@ -90,7 +92,7 @@ def test_random_problem_matches_oracle(case, monkeypatch):
 def test_random_sharded_plan_matches_oracle(case, monkeypatch):
     """The same draw through ResidentPlan, sharded over 2..5 ranks with the thresholds exchanged inside the joins: the
     merged null maxima and top-k are the oracle's."""
-    cfg, env = draw(100000 + case)
+    cfg, env = draw(BASE + 100000 + case)
     env["GCRE_WINDOW_TILES"] = ""
     env["GCRE_EXCHANGE_UNIT"] = str([5, 50, 2000][case % 3])
     env["GCRE_PIVOT_SHARDS"] = "1" if case % 2 else ""
@@ -110,7 +112,7 @@ def test_random_sharded_plan_matches_oracle(case, monkeypatch):
 def test_random_resident_plan_with_kept_inspections(case, monkeypatch):
     """ResidentPlan over the same draw: a pass, a pass that keeps its inspections, a pass that replays them under another
     permutation window -- each the oracle's."""
-    cfg, env = draw(200000 + case)
+    cfg, env = draw(BASE + 200000 + case)
     env["GCRE_WINDOW_TILES"] = ""
     for k, v in env.items():
         if v:
