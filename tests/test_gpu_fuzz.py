@@ -134,3 +134,21 @@ def test_random_resident_plan_with_kept_inspections(case, monkeypatch):
                 assert_same_result(got[name], want[f"lst{lvl}"])
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize("case", range(max(1, N_CASES // 4)))
+def test_random_problem_on_several_device_threads(case, monkeypatch):
+    """gcre_process_paths_devices with device 0 listed 2..4 times (one context and host thread each, shards, the host-side
+    threshold hub inside the joins): the oracle's results."""
+    cfg, env = draw(BASE + 300000 + case)
+    env["GCRE_EXCHANGE_UNIT"] = str([5, 50, 2000][case % 3])
+    for k, v in env.items():
+        if v:
+            monkeypatch.setenv(k, v)
+    p = make_problem(cfg["genes"], cfg["edges"], cfg["n_cases"], cfg["n_ctrls"], cfg["perms"], cfg["length"],
+                     method=cfg["method"], top_k=cfg["top_k"], seed=cfg["seed"], threshold=cfg["threshold"],
+                     table=value_table(cfg["table"], cfg["n_cases"], cfg["n_ctrls"], cfg["seed"]))
+    want = oracle.process_paths(p, order="canonical")
+    got = api.process_paths_devices(p, devices=[0] * (2 + case % 3))
+    for lvl in range(1, cfg["length"] + 1):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
