@@ -54,6 +54,9 @@ def draw(case: int):
             n_cases = int(rng.integers(2, 12))
     if case % 11 == 5:     # wider rows
         n_cases, n_ctrls = int(rng.integers(400, 1100)), int(rng.integers(400, 1100))
+    wide = case % 13 == 6     # BASELINE configs[2] width: ~5,000 patients, 79-82 mask words
+    if wide:
+        n_cases, n_ctrls = int(rng.integers(2300, 2700)), int(rng.integers(2300, 2700))
     genes = int(rng.integers(25, 90))
     edges = int(rng.integers(genes * 2, genes * 5))
     length = int(rng.choice([3, 4, 4, 5]))
@@ -64,6 +67,8 @@ def draw(case: int):
     if length == 5:
         edges = min(edges, genes * 3)
     perms = int(rng.choice([0, 1, 31, 100, 257, 2048, 2300, 4500]))
+    if wide:
+        perms = min(perms, 2300)
     method = str(rng.choice(["method1", "method1", "method2"]))
     threshold = float(rng.choice([0.02, 0.05, 0.05, 0.15, 0.4, 0.9]))
     top_k = int(rng.choice([1, 7, 15, 40, 3000]))
