@@ -57,8 +57,17 @@ def draw(case: int):
     wide = case % 13 == 6     # BASELINE configs[2] width: ~5,000 patients, 79-82 mask words
     if wide:
         n_cases, n_ctrls = int(rng.integers(2300, 2700)), int(rng.integers(2300, 2700))
+    huge = case % 29 == 7      # 100-160 mask words: the inspector's 4- and 5-block forms (two waves per SIMD)
+    if huge:
+        n_cases, n_ctrls = int(rng.integers(3200, 5100)), int(rng.integers(3200, 5100))
+    beyond = case % 31 == 9    # past 10,240 patients: the per-path inspector, wider planes
+    if beyond:
+        n_cases, n_ctrls = int(rng.integers(5200, 6000)), int(rng.integers(5100, 6000))
     genes = int(rng.integers(25, 90))
     edges = int(rng.integers(genes * 2, genes * 5))
+    if huge or beyond:
+        genes = int(rng.integers(25, 45))
+        edges = int(rng.integers(genes * 2, genes * 4))
     length = int(rng.choice([3, 4, 4, 5]))
     if case % 5 == 4:      # a larger network: thousands of segments per join, quads, several chunks of work per wave
         genes = int(rng.integers(150, 320))
@@ -69,6 +78,8 @@ def draw(case: int):
     perms = int(rng.choice([0, 1, 31, 100, 257, 2048, 2300, 4500]))
     if wide:
         perms = min(perms, 2300)
+    if huge or beyond:
+        perms = min(perms, 257)
     method = str(rng.choice(["method1", "method1", "method2"]))
     threshold = float(rng.choice([0.02, 0.05, 0.05, 0.15, 0.4, 0.9]))
     top_k = int(rng.choice([1, 7, 15, 40, 3000]))
