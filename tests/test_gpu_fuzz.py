@@ -16,6 +16,7 @@ from test_gpu_exchange import check_merged, run_ranks
 pytestmark = pytest.mark.gpu
 
 N_CASES = int(os.environ.get("GCRE_FUZZ_CASES", "8"))
+LIGHT = os.environ.get("GCRE_FUZZ_LIGHT") == "1"       # bulk runs: no cohorts past 6,000 patients (their oracle runs take seconds)
 BASE = int(os.environ.get("GCRE_FUZZ_BASE", "0"))      # another stretch of the case numbers
 KNOBS = {
     "GCRE_NULL_KERNEL": ["", "ie", "ie", "ie", "sparse", "dense"],
@@ -57,10 +58,10 @@ def draw(case: int):
     wide = case % 13 == 6     # BASELINE configs[2] width: ~5,000 patients, 79-82 mask words
     if wide:
         n_cases, n_ctrls = int(rng.integers(2300, 2700)), int(rng.integers(2300, 2700))
-    huge = case % 29 == 7      # 100-160 mask words: the inspector's 4- and 5-block forms (two waves per SIMD)
+    huge = case % 29 == 7 and not LIGHT     # 100-160 mask words: the inspector's 4- and 5-block forms (two waves per SIMD)
     if huge:
         n_cases, n_ctrls = int(rng.integers(3200, 5100)), int(rng.integers(3200, 5100))
-    beyond = case % 31 == 9    # past 10,240 patients: the per-path inspector, wider planes
+    beyond = case % 31 == 9 and not LIGHT   # past 10,240 patients: the per-path inspector, wider planes
     if beyond:
         n_cases, n_ctrls = int(rng.integers(5200, 6000)), int(rng.integers(5100, 6000))
     genes = int(rng.integers(25, 90))
