@@ -1882,7 +1882,8 @@ hipError_t launch_range_union(const uint64_t* p1, const uint64_t* pz, const int3
 // NL = 16-byte loads per row and lane = ceil(Wp / 32) (Wp <= 32 * NL).
 // ------------------------------------------------------------------------------------------------
 #ifndef GCRE_STATS_WAVES
-#define GCRE_STATS_WAVES 4   // 10 spilled registers at four waves per SIMD, and still faster than three (6.26 against 6.72 ms per pass)
+#define GCRE_STATS_WAVES 4   // 122 VGPRs with one set of row registers (below): four waves per SIMD without a spill; 6.0 against 6.7 ms per
+                             // pass at three.  Five (96 VGPRs, 27 spilled, the pair buffer flushed in chunks to fit the LDS): 8.1 ms
 #endif
 template <int NL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? GCRE_STATS_WAVES : 2))) void k_stats_ie2(const StatsArgs a) {
