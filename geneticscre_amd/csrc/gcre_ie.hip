@@ -2003,6 +2003,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? G
       const u32 mode = a.ie_rule ? ((ov <= 8u || ov < dl) ? 1u : 0u) : ((a.ie_bias >= 0 && ov + (u32)a.ie_bias < dl) ? 1u : 0u);
       const u32 len = mode ? ov : dl;
       const u32 len8 = max(8u, (len + 7u) & ~7u);
+      // The list's bits are few and scattered -- three overlapping patients among a path's 96 lane-words -- so a loop per
+      // word runs its body for one lane at a time.  Instead the non-zero words are first collected per group (word, its
+      // index; positions from a ballot), then every lane takes one collected word and all of them give up a bit per round:
+      // two rounds instead of eight bodies.  Entries come out in collection order, not ascending (the list is a set).
+      u32 npair = 0u;
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const u64 w = mode ? (zw[it][e] & xw[it][e]) : (zw[it][e] & ~xw[it][e]);
+          const bool nz = active && w != 0;
+          const u64 bal = __builtin_amdgcn_ballot_w64(nz);
+          if (bal == 0ull) continue;
+          const u32 m = (u32)(bal >> gsh) & 0xffffu;
+          const u32 at = npair + (u32)__builtin_popcount(m & ltm);
+          if (nz) {
+            pairs[0][at] = (u32)w;
+            pairs[1][at] = (u32)(w >> 32);
+            pairs[2][at] = (u32)(it * 32 + 2 * sl + e);
+          }
+          npair += (u32)__builtin_popcount(m);
+        }
+      }
+      fetch_rows(it4 < 15 ? it4 + 1 : 15);   // (changes rz / rng of the NEXT iteration only: this one read them above)
       double score = 0.0;
       if (active && sl == 0) {
         my_modes += mode;
@@ -2029,30 +2053,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? G
       }
       const bool ov_ok = active && len8 > 8u && (u64)ovb + (len8 - 8u) <= (u64)a.over_cap;
       u32* over = a.over + ovb;
-      // The list's bits are few and scattered -- three overlapping patients among a path's 96 lane-words -- so a loop per
-      // word runs its body for one lane at a time.  Instead the non-zero words are first collected per group (word, its
-      // index; positions from a ballot), then every lane takes one collected word and all of them give up a bit per round:
-      // two rounds instead of eight bodies.  Entries come out in collection order, not ascending (the list is a set).
-      u32 npair = 0u;
-#pragma unroll
-      for (int it = 0; it < NL; it++) {
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-          const u64 w = mode ? (zw[it][e] & xw[it][e]) : (zw[it][e] & ~xw[it][e]);
-          const bool nz = active && w != 0;
-          const u64 bal = __builtin_amdgcn_ballot_w64(nz);
-          if (bal == 0ull) continue;
-          const u32 m = (u32)(bal >> gsh) & 0xffffu;
-          const u32 at = npair + (u32)__builtin_popcount(m & ltm);
-          if (nz) {
-            pairs[0][at] = (u32)w;
-            pairs[1][at] = (u32)(w >> 32);
-            pairs[2][at] = (u32)(it * 32 + 2 * sl + e);
-          }
-          npair += (u32)__builtin_popcount(m);
-        }
-      }
-      fetch_rows(it4 < 15 ? it4 + 1 : 15);   // (changes rz / rng of the NEXT iteration only: this one read them above)
       __builtin_amdgcn_wave_barrier();
       {
         const u32 npmax = max(max(rdlane(npair, 0), rdlane(npair, 16)), max(rdlane(npair, 32), rdlane(npair, 48)));
