@@ -27,6 +27,11 @@ KNOBS = {
     "GCRE_IE_BATCH": ["", "1", "5"],
     "GCRE_WINDOW_TILES": ["", "", "1", "2"],
     "GCRE_PLANES_OUT_MAX_MB": ["", "", "0"],
+    "GCRE_CHUNK_PATHS": ["", "", "700", "5000"],        # several chunks per join: shard and recipe boundaries inside a join
+    "GCRE_SELECT_STREAM": ["", "", "0"],
+    "GCRE_PREFETCH_TABLES": ["", "0"],
+    "GCRE_SPARSE_WAVES_PER_CU": ["", "", "4", "16"],
+    "GCRE_IE_SJT": ["", "1", "64"],
 }
 
 
