@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libgcre_hip.so")
-SOURCES = ["gcre_kernels.hip", "gcre_sparse.hip", "gcre_ie.hip", "gcre_ieq.hip", "gcre_frontend.hip", "gcre_host.hip"]
+SOURCES = ["gcre_kernels.hip", "gcre_sparse.hip", "gcre_ie.hip", "gcre_ie2.hip", "gcre_ieq.hip", "gcre_frontend.hip", "gcre_host.hip"]
 HEADERS = ["gcre_kernels.h", "gcre_bitslice.h", "gcre_ie_common.h", os.path.join("..", "..", "include", "gcre_hip.h")]
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 # Defines that switch parts of a kernel off for timing experiments ("results are wrong") must never reach the shipped

@@ -290,7 +290,7 @@ struct InspSwap {
   }
 };
 
-// How a kept path set was made (method 1): row r = row row0[r] of set A | row rowz[r] of set Z, with the producing
+// How a kept path set was made: row r = row row0[r] of set A | row rowz[r] of set Z, with the producing
 // join's list (the overlap of the two rows, or what Z adds) as its inspector left it.  Enough to rebuild the count
 // planes of any row for any permutation tile from the planes of A and Z, so the set's own planes (3 KB per row and
 // tile) need not be stored, written or read.  Independent of the masks.
@@ -1348,7 +1348,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     if (want_ie) {
       if (int rc = prepare_z()) return rc;
       have_p0 = planes_cover(c, jp.p0, r_lo, r_hi);        // a kept join left them behind
-      if (!have_p0 && g.method == 1 && recipe_operands(c, jp.p0, &rec_a, &rec_z)) {
+      if (!have_p0 && recipe_operands(c, jp.p0, &rec_a, &rec_z)) {
         // ... or it left the recipe: the kernel rebuilds a row's planes from the planes of the recipe's operands
         // (of which a multi-device run may hold a range only: the rows the recipe of [r_lo, r_hi) names -- the
         // producing join's paths0 rows, ascending)
@@ -1394,20 +1394,21 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         const uint32_t bound = std::min<uint32_t>((uint32_t)(64 * g.Wp), row_max(c, jp.p0) + row_max(c, red));
         const int out_groups = plane_groups_for(bound);
         bool want_out = true;
-        if (g.method == 1) {
-          // the kept rows leave with the recipe of this join (its inspector output, 60 B per row).  Their planes are only
-          // written when they are small, or when the next join could not use the recipe (it needs stored planes of paths0)
+        {
+          // the kept rows leave with the recipe of this join (its inspector output: 60 B per row, 104 B for the signed
+          // method's two lists).  Their planes are only written when they are small, or when the next join could not use the
+          // recipe (it needs stored planes of paths0)
           if (!jp.res->rec) jp.res->rec = new gcre_recipe();
           rcp = jp.res->rec;
           if (!replay) rcp->valid = false;
-          const size_t rows = (size_t)P;
+          const size_t rows = (size_t)P, lists = rows * (size_t)g.method;
           hipError_t e = rcp->row0.reserve(rows + 64);
           if (e == hipSuccess) e = rcp->rowz.reserve(rows + 64);
-          if (e == hipSuccess) e = rcp->linfo.reserve(rows + 64);
-          if (e == hipSuccess) e = rcp->lover.reserve(rows + 64);
-          if (e == hipSuccess) e = rcp->tot.reserve(rows + 64);
-          if (e == hipSuccess) e = rcp->slot.reserve(rows * 8 + 64);
-          if (e == hipSuccess) e = rcp->over.reserve(std::max<size_t>(rcp->over.cap, rows * 2 + ((size_t)1 << 26)));
+          if (e == hipSuccess) e = rcp->linfo.reserve(lists + 64);
+          if (e == hipSuccess) e = rcp->lover.reserve(lists + 64);
+          if (e == hipSuccess) e = rcp->tot.reserve(lists + 64);
+          if (e == hipSuccess) e = rcp->slot.reserve(lists * 8 + 64);
+          if (e == hipSuccess) e = rcp->over.reserve(std::max<size_t>(rcp->over.cap, lists * 2 + ((size_t)1 << 26)));
           if (e != hipSuccess) {
             (void)hipGetLastError();
             rcp->release();
@@ -1566,9 +1567,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sa.ie_rule = g.method == 1 ? 1 : 0;   // the bound filter and the quad kernel want overlap lists
           if (rcp) {   // straight into the recipe of the kept set (absolute row = cb + i)
             sa.rowz = rcp->rowz.p + cb;
-            sa.linfo = rcp->linfo.p + cb;
-            sa.lover = rcp->lover.p + cb;
-            sa.slot = rcp->slot.p + (size_t)cb * 8;
+            sa.linfo = rcp->linfo.p + (size_t)cb * g.method;
+            sa.lover = rcp->lover.p + (size_t)cb * g.method;
+            sa.slot = rcp->slot.p + (size_t)cb * g.method * 8;
             sa.over = rcp->over.p;
             sa.over_cap = (uint32_t)std::min<size_t>(rcp->over.cap - 16, 0xfffffff0u);
             if (!hit) HIP_TRY(c, hipMemcpyAsync(rcp->row0.p + cb, c->d_row0.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
@@ -1584,7 +1585,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           sa.zoff = (uint32_t)(64 * g.Wp) << 8;
           if (!hit) HIP_TRY(c, launch_stats_ie(sa, g.method, st));
           // a kept row's carrier total bounds every count of it: the next level loads only the plane groups that can be non-zero
-          if (rcp && !hit) HIP_TRY(c, hipMemcpyAsync(rcp->tot.p + cb, c->d_tot.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+          if (rcp && !hit) HIP_TRY(c, hipMemcpyAsync(rcp->tot.p + (size_t)cb * g.method, c->d_tot.p, (size_t)n * g.method * 4, hipMemcpyDeviceToDevice, st));
         } else if (!hit) {
           HIP_TRY(c, launch_stats(sa, g.method, st));
         }
@@ -1695,9 +1696,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.rows_out = res_planes ? (uint32_t)(jp.res->nrows * g.method) : 0u;
           ia.loff0 = jp.p0->d_loff;
           ia.lidx0 = jp.p0->d_lidx;
-          ia.linfo = rcp ? rcp->linfo.p + cb : c->d_linfo.p;
-          ia.lover = rcp ? rcp->lover.p + cb : c->d_lover.p;
-          ia.dlist = rcp ? rcp->slot.p + (size_t)cb * 8 : c->d_dlist.p;
+          ia.linfo = rcp ? rcp->linfo.p + (size_t)cb * g.method : c->d_linfo.p;
+          ia.lover = rcp ? rcp->lover.p + (size_t)cb * g.method : c->d_lover.p;
+          ia.dlist = rcp ? rcp->slot.p + (size_t)cb * g.method * 8 : c->d_dlist.p;
           ia.dover = rcp ? rcp->over.p : c->d_dover.p;
           if (use_rec) {
             const gcre_recipe* r0 = jp.p0->rec;
@@ -1709,15 +1710,17 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             ia.rec_over = r0->over.p;
             ia.rec_planes_a = rec_a->d_planes;
             ia.rec_planes_z = rec_z->d_planes;
-            ia.rec_rows_a = (uint32_t)rec_a->nrows;
-            ia.rec_rows_z = (uint32_t)rec_z->nrows;
+            ia.rec_rows_a = (uint32_t)(rec_a->nrows * g.method);   // row-halves
+            ia.rec_rows_z = (uint32_t)(rec_z->nrows * g.method);
             ia.rec_ga = rec_a->plane_groups;
             ia.rec_gz = rec_z->plane_groups;
-            // the recipe entries of every segment's row, next to the segment table (no load depends on row0 any more)
-            HIP_TRY(c, c->d_rec_segs.reserve((size_t)std::max<int64_t>(ia.nsegs, 1) * kRecSegWords));
-            HIP_TRY(c, launch_fill_rec_segs(ia.segs, ia.nsegs, r0->row0.p, r0->rowz.p, r0->linfo.p, r0->lover.p, r0->slot.p, r0->tot.p,
-                                            c->d_rec_segs.p, st));
-            ia.rec_segs = c->d_rec_segs.p;
+            if (g.method == 1) {
+              // the recipe entries of every segment's row, next to the segment table (no load depends on row0 any more)
+              HIP_TRY(c, c->d_rec_segs.reserve((size_t)std::max<int64_t>(ia.nsegs, 1) * kRecSegWords));
+              HIP_TRY(c, launch_fill_rec_segs(ia.segs, ia.nsegs, r0->row0.p, r0->rowz.p, r0->linfo.p, r0->lover.p, r0->slot.p, r0->tot.p,
+                                              c->d_rec_segs.p, st));
+              ia.rec_segs = c->d_rec_segs.p;
+            }
           }
           ia.t32 = c->d_t32;
           ia.d64 = c->d_dmax;
@@ -2452,12 +2455,12 @@ int gcre_plan_perm_window(gcre_ctx* c, const int64_t* set_rows, int n_sets) {
   (void)hipSetDevice(c->device);
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return K;
-  // sets that store their planes: all of them for the signed method; for method 1 the ones under the recipe limit
-  // (larger kept sets leave a recipe instead, and operands that are not kept are small)
+  // sets that store their planes: the ones under the recipe limit (larger kept sets leave a recipe instead, and operands
+  // that are not kept are small)
   double rows = 1;
   for (int i = 0; i < n_sets; i++) {
     const double full = (double)std::max<int64_t>(set_rows[i], 0) * c->g.method * 4096.0 * nkt;
-    if (c->g.method != 1 || full <= (double)c->planes_out_max) rows += (double)std::max<int64_t>(set_rows[i], 0);
+    if (full <= (double)c->planes_out_max) rows += (double)std::max<int64_t>(set_rows[i], 0);
   }
   const double per_tile = rows * c->g.method * 4096.0;
   int64_t tiles = (int64_t)((double)free_b * 0.5 / per_tile);
@@ -2845,12 +2848,12 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     // A context without a pooled plane buffer of the full size (the R shim makes a fresh context per call, as the
     // reference does) has to hipMalloc the planes: ~40 ms per GB here, 3 KB per kept row and tile.  Against ~25 ms of
     // repeated inspector work per extra window, few tiles per window win: w* = sqrt(25 ms * tiles / (ms per tile)).
-    // (Method 1: a set above the recipe limit stores no planes.)
+    // (A set above the recipe limit stores no planes.)
     const int nkt_all = (Kall + kSparseTile - 1) / kSparseTile;
     int64_t biggest = 0;
     for (size_t i = 2; i < set_rows.size(); i++) {
       const double full = (double)set_rows[i] * c->g.method * 3072.0 * nkt_all;
-      if (c->g.method != 1 || full <= (double)c->planes_out_max) biggest = std::max(biggest, set_rows[i]);
+      if (full <= (double)c->planes_out_max) biggest = std::max(biggest, set_rows[i]);
     }
     const double ms_per_tile = (double)biggest * c->g.method * 3072.0 / 1e9 * 40.0;
     const size_t full_bytes = (size_t)biggest * c->g.method * 3072 * (size_t)((win + kSparseTile - 1) / kSparseTile);
@@ -2938,7 +2941,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       PP_REQUIRE(paths2);
       // the sequence is known here: when level 3's rows are too many to leave with count planes they leave with a recipe
       // whose operand is this set -- which then must not be recipe-only itself (it would be rebuilt from bit lists)
-      if (L >= 4 && c->g.method == 1 && plane_bytes(c, total_paths(in->level[3]), 2) > c->planes_out_max) paths2->planes_wanted = true;
+      if (L >= 4 && plane_bytes(c, total_paths(in->level[3]), 2) > c->planes_out_max) paths2->planes_wanted = true;
       // the reference reads data_idx2 from r_data_inds3 (wrapper.cpp:207); R passes identical vectors
       if (!input_l2) temps.push_back(input_l2 = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]));
       gcre_pathset* const input = input_l2;

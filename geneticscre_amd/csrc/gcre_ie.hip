@@ -201,17 +201,19 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(M
         const u64 r = (u64)row0 * M + h;
         if (a.planes0) {
           load_planes(B[h], a.planes0, (u32)(((u64)kt * (u64)a.rows0 + r) * (u64)a.g0), a.g0);
-        } else if (M == 1 && a.rec_slot) {
-          // the set has the recipe of the join that made it (see k_null_ie_m1): A[row0'] + Z[z'] -/+ that join's list
-          const u32 ra = a.rec_row0[row0], rz = a.rec_rowz[row0] & 0x7fffffffu, rinfo = a.rec_linfo[row0];
+        } else if (a.rec_slot) {
+          // the set has the recipe of the join that made it (see k_null_ie_m1 / k_null_ie_m2): per half
+          // A[row0'][h] + Z[z'][h'] -/+ that join's list of the half (rec_rows_a / rec_rows_z count row-halves)
+          const u32 ra = a.rec_row0[row0], rzr = a.rec_rowz[row0], rz = rzr & 0x7fffffffu, rinfo = a.rec_linfo[r];
+          const u32 hz = (M == 2 && (rzr >> 31)) ? (u32)(1 - h) : (u32)h;
           u32 ZR[L], S[L];
-          load_planes(B[h], a.rec_planes_a, (u32)(((u64)kt * (u64)a.rec_rows_a + ra) * (u64)a.rec_ga), a.rec_ga);
-          load_planes(ZR, a.rec_planes_z, (u32)(((u64)kt * (u64)a.rec_rows_z + rz) * (u64)a.rec_gz), a.rec_gz);
+          load_planes(B[h], a.rec_planes_a, (u32)(((u64)kt * (u64)a.rec_rows_a + (u64)ra * M + h) * (u64)a.rec_ga), a.rec_ga);
+          load_planes(ZR, a.rec_planes_z, (u32)(((u64)kt * (u64)a.rec_rows_z + (u64)rz * M + hz) * (u64)a.rec_gz), a.rec_gz);
 #pragma unroll
           for (int l = 0; l < L; l++) S[l] = 0u;
           const u32 rlen = rinfo & kLinfoLenMask;
-          stream(S, (const u32 GCRE_CONSTANT*)(a.rec_slot + (u64)row0 * 8u), 0, 8);
-          if (rlen > 8u) stream(S, (const u32 GCRE_CONSTANT*)(a.rec_over + a.rec_lover[row0]), 0, (u64)(rlen - 8u));
+          stream(S, (const u32 GCRE_CONSTANT*)(a.rec_slot + r * 8u), 0, 8);
+          if (rlen > 8u) stream(S, (const u32 GCRE_CONSTANT*)(a.rec_over + a.rec_lover[r]), 0, (u64)(rlen - 8u));
           u32 cy = 0u, bw = 0u;
 #pragma unroll
           for (int l = 0; l < L; l++) {
@@ -907,376 +909,12 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
   if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
 }
 
-// ------------------------------------------------------------------------------------------------
-// method 2 (signed), pruned.  A joined path has a (+) and a (-) half with their own counts a, b and carrier totals
-// tp, tn; its null score is (float)(F + G), F = vtmax[tp][a], G = vtmax[tn][b] (methods.h:220-230).  For a threshold
-// theta not above any running maximum of the tile and any split ha + hb <= theta, a permutation with (F <= ha and
-// G <= hb) or (F <= hb and G <= ha) cannot raise its maximum (the f64 sum is <= theta, rounding to f32 is monotone).
-// With ha ~ theta/3, hb ~ 2 theta/3 the two rectangles leave ~3 exp(-2 theta / 3) of the permutations, against
-// 2 exp(-theta / 2) for the single square (theta/2, theta/2): 14 % instead of 93 % of the path-tiles reach a lookup at
-// configs[2] geometry.  Both halves are tested against the intervals of their diagonals for ha and hb
-// (k_build_ladder2, four borrow-chain tests); what fails both rectangles is looked up exactly: both cells gathered in
-// f64, added, rounded, clamped at 0.
-// ------------------------------------------------------------------------------------------------
-template <int L, int GZ, bool OUT>
-__global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L <= 10 ? 4 : 3))) void k_null_ie_m2(const IeArgs a) {
-  constexpr int LP = (L + 3) / 4 * 4;
-  constexpr int LZ = 4 * GZ;   // planes of an added row (GZ groups; the launch picks GZ >= a.gz)
-  static_assert(LZ <= LP, "added rows have no more planes than joined paths");
-  static_assert(L >= 8 && L <= 16, "8 to 16 counter planes");
-  typedef u32 __attribute__((ext_vector_type(8))) u32x8;
-  __shared__ u32 nmax_lds[kIeWaves][32 * 64];
-  // Look-ups are QUEUED, not made where they are found (round 3).  A look-up is two dependent-latency f64 gathers into
-  // 100-MB tables; made on the spot -- one or two permutations of one path at a time -- the wave sat out a full memory round
-  // trip per path (with the look-ups compiled out the signed pass's null kernels took 35 instead of 82 ms).  Here a
-  // permutation that fails both rectangles only leaves (cell of F, cell of G, slot of its maximum) in the wave's LDS queue;
-  // when 64 are waiting (or the tile ends) every lane takes one, and ONE round trip serves 64 look-ups.  Maxima may lag a
-  // queue behind: a threshold read meanwhile is only lower, never wrong.
-  constexpr u32 kLqCap = 128u;
-  __shared__ u32 lq_lds[kIeWaves][3][kLqCap];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const u32 lane4 = (u32)lane * 4u;
-  u32* nm = nmax_lds[wave] + lane;
-#pragma unroll
-  for (int q = 0; q < 32; q++) nm[q * 64] = 0u;
-  const SparseSeg GCRE_CONSTANT* segs = (const SparseSeg GCRE_CONSTANT*)a.segs;
-  u32 (*lq)[kLqCap] = lq_lds[wave];
-  u32 lq_n = 0u;   // entries waiting (wave-uniform)
-  auto lq_drain = [&]() {
-    for (u32 base = 0u; base < lq_n; base += 64u) {
-      const u32 i = base + (u32)lane;
-      if (i < lq_n) {
-        const double f64 = a.d64[lq[0][i]] + a.d64[lq[1][i]];   // vtmax[tp][a] + vtmax[tn][b], methods.h:227
-        float f = (float)f64;
-        f = (f > 0.0f) ? f : 0.0f;
-        __hip_atomic_fetch_max(nmax_lds[wave] + lq[2][i], __float_as_uint(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
-    }
-    lq_n = 0u;
-  };
-
-  int cur_kt = -1;
-  u32 valid = 0u;
-  // two ladder rows: thresholds ha + hb <= theta (about theta/3 and 2 theta/3), rows are in units of 1/(2 kLadderPerUnit)
-  u32 lad_a = (a.lad_mode == 0) ? 0u : (u32)(kLadder2Levels - 1 + a.lad_mode) * (u32)a.ladder_stride;
-  u32 lad_b = lad_a;
-  const u32 lad_keep = (u32)kLadder2Levels * (u32)a.ladder_stride;
-  bool dirty = false;
-  u32 n_slow = 0u;
-  __amdgpu_buffer_rsrc_t mt = __builtin_amdgcn_make_buffer_rsrc((void*)a.mt, 0, 0x7fffffff, 0x00020000);
-
-  auto exchange = [&]() {
-    u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
-    __amdgpu_buffer_rsrc_t nb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.null_bits + (size_t)cur_kt * 2048), 0, 8192, 0x00020000);
-    u32x4 g4[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) g4[j] = __builtin_amdgcn_raw_buffer_load_b128(nb, (u32)lane * 128u + (u32)j * 16u, 0, 16 /* sc1 */);
-    u32 lo = 0xffffffffu;
-#pragma unroll
-    for (int q = 0; q < 32; q++) {
-      const u32 g = g4[q >> 2][q & 3];
-      const u32 own = nm[q * 64];
-      if (dirty && own > g) atomicMax(out + q, own);
-      const u32 v = own > g ? own : g;
-      if ((valid >> q) & 1u) lo = v < lo ? v : lo;
-    }
-    dirty = false;
-    u32 theta = __builtin_amdgcn_readfirstlane(wave_min_u32(lo));
-    if (theta == 0xffffffffu) theta = 0u;
-    int j = (int)(__uint_as_float(theta) * (float)kLadderPerUnit);   // theta >= j / kLadderPerUnit = 2 j rows
-    j = j < 0 ? 0 : (j > kLadderLevels - 1 ? kLadderLevels - 1 : j);
-    const int ra = (2 * j) / 3;
-    int rb = 2 * j - ra;
-    rb = rb > kLadder2Levels - 1 ? kLadder2Levels - 1 : rb;
-    lad_a = (u32)ra * (u32)a.ladder_stride;
-    lad_b = (u32)rb * (u32)a.ladder_stride;
-  };
-  auto flush_tile = [&]() {
-    lq_drain();
-    if (cur_kt >= 0) {
-      u32* out = a.null_bits + (size_t)cur_kt * 2048 + lane * 32;
-#pragma unroll 8
-      for (int q = 0; q < 32; q++) {
-        const u32 own = nm[q * 64];
-        if (own != 0u) {
-          atomicMax(out + q, own);
-          nm[q * 64] = 0u;
-        }
-      }
-    }
-    dirty = false;
-  };
-  auto load_groups = [&](u32 (&P)[LP], const u32* planes, u64 unit, int groups) {
-    const u32x4* src = (const u32x4*)(planes + unit * 256u) + lane;
-#pragma unroll
-    for (int j = 0; j < LP / 4; j++) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (j < groups) v = src[j * 64];
-      P[4 * j + 0] = v.x; P[4 * j + 1] = v.y; P[4 * j + 2] = v.z; P[4 * j + 3] = v.w;
-    }
-  };
-  // live permutations whose count lies outside [lo, hi] (bounds as scalar masks, two borrow chains)
-  auto outside = [&](const auto& C, u32 lh) -> u32 {   // C: at least L planes
-    const u32 lo = lh & 0xffffu, hi = lh >> 16;
-    u32 blo = 0u, bhi = 0u;
-#pragma unroll
-    for (int l = 0; l < L; l++) {
-      const u32 kl = (u32)__builtin_amdgcn_sbfe((int)lo, l, 1);
-      const u32 kh = (u32)__builtin_amdgcn_sbfe((int)hi, l, 1);
-      blo = borrow3(C[l], kl, blo);
-      bhi = borrow3(kh, C[l], bhi);
-    }
-    return blo | bhi;
-  };
-
-  // work queues as in k_null_ie_m1
-  __shared__ u32 wq_state[kIeWaves][8];
-  WorkQueue wq;
-  wq.st = wq_state[wave];
-  wq.init(a.queue, (u32)((a.seg_end - a.seg_begin + a.batch - 1) / a.batch), (u32)a.nkt);
-  {
-    wq.select(blockIdx.x & 7u);   // workgroups are dealt round the XCDs: blocks b and b + 8 share an L2
-  }
-  u32 ticket = wq.take(lane);
-  int since = 0, period = 1;
-  for (;;) {
-    const u32 work = __builtin_amdgcn_readfirstlane(ticket);
-    const u32 q_n = wq.get(2);
-    if (work >= q_n) {
-      // this queue is empty: take from the fullest one; every wave ends once it has seen them all empty
-      if (!wq.steal(lane)) break;
-      ticket = wq.take(lane);
-      continue;
-    }
-    ticket = wq.take(lane);   // the next ticket is on its way while this batch is worked on
-    const u32 item = wq.get(1) + work, nb = wq.get(3);
-    const int kt = (int)(item / nb);
-    const i64 s_lo = a.seg_begin + (i64)(item - (u32)kt * nb) * a.batch;
-    const i64 s_hi = s_lo + a.batch < a.seg_end ? s_lo + a.batch : a.seg_end;
-    if (kt != cur_kt) {
-      flush_tile();
-      cur_kt = kt;
-      mt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mt + (size_t)kt * a.mt_rows * 64), 0, 0x7fffffff, 0x00020000);
-      const int live = a.K - kt * 2048 - lane * 32;
-      valid = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : ((1u << live) - 1u));
-      if (a.lad_mode == 0) lad_a = lad_b = 0u;
-      since = 0;
-      period = 1;
-    }
-    for (i64 sidx = s_lo; sidx < s_hi; sidx++) {
-      const u32 row0 = segs[sidx].row0;
-      const u32 first = segs[sidx].first;
-      const u32 npaths = segs[sidx].n;
-      if (a.lad_mode == 0 && ++since >= period) {
-        exchange();
-        since = 0;
-        period = period < kIeRefresh ? period * 2 : kIeRefresh;
-      }
-      // ---- per-path metadata of the segment: lane t <-> joined path first + t, both halves ----
-      const u32 qv = first + (((u32)lane < npaths) ? (u32)lane : 0u);
-      const u32 rzv = a.rowz[qv];
-      const bool mine = (u64)sidx < (u64)a.score_segs;   // else: rows of another shard, the ladder's all-inside row
-      u32 infov[2], lovv[2], zunit[2], totv[2], lha[2], lhb[2];
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        infov[h] = a.linfo[(u64)qv * 2 + h];
-        lovv[h] = a.lover[(u64)qv * 2 + h];
-        const u32 hz = (rzv >> 31) ? (u32)(1 - h) : (u32)h;
-        zunit[h] = ((u32)kt * (u32)a.rowsz + (rzv & 0x7fffffffu) * 2u + hz) * (u32)a.gz;
-        totv[h] = a.tot[(u64)qv * 2 + h];
-        lha[h] = a.ladder[(mine ? lad_a : lad_keep) + totv[h]];
-        lhb[h] = a.ladder[(mine ? lad_b : lad_keep) + totv[h]];
-      }
-      const u32x8 GCRE_CONSTANT* slots = (const u32x8 GCRE_CONSTANT*)(a.dlist + (u64)first * 16u);
-      u32 B[2][LP];
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-        load_groups(B[h], a.planes0, ((u64)kt * (u64)a.rows0 + (u64)row0 * 2 + h) * (u64)a.g0, a.g0);
-
-      // ---- the joined paths of the segment, half by half, software-pipelined one half ahead (as k_null_ie_m1): the
-      // mask rows and planes of the next half are in flight while this one is added up.  (+) halves use buffer A,
-      // (-) halves buffer B; the last path is simply requested twice. ----
-      const u32 last = npaths - 1u;
-      auto at = [&](u32 t2) -> u32 { return t2 < last ? t2 : last; };
-      auto issue = [&](int h, u32 t2, const u32x8 offs, u32 (&yy)[8], u32 (&ZZ)[LZ]) {
-        // A wave-load costs the memory pipe the same whatever it fetches (profiles/r02_row_gather_rate.txt), and most
-        // lists are short: one half of a gene row is empty (an empty delta list), the other overlaps the path in a patient
-        // or two.  Only the entries that are not padding are fetched, in steps of four: 0, 4 or 8 loads instead of 8.
-        const u32 info = rdlane(infov[h], t2);
-        const u32 real = (info & kLinfoLenMask) - (info >> 28);
-        if (real > 4u) {
-#pragma unroll
-          for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
-        } else if (real > 0u) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
-#pragma unroll
-          for (int j = 4; j < 8; j++) yy[j] = 0u;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; j++) yy[j] = 0u;
-        }
-        if (info & 1u) {   // overlap lists only
-          const u32x4* src = (const u32x4*)(a.planesz + (u64)rdlane(zunit[h], t2) * 256u) + lane;
-#pragma unroll
-          for (int j = 0; j < GZ; j++) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (j < a.gz) v = src[j * 64];
-            ZZ[4 * j + 0] = v.x; ZZ[4 * j + 1] = v.y; ZZ[4 * j + 2] = v.z; ZZ[4 * j + 3] = v.w;
-          }
-        }
-      };
-      u32 C[2][L];
-      // interval tests of a half whose list is empty: its counts are the segment's base counters, its carrier total the
-      // segment's -- the same two results for every such path of the segment
-      u32 eA[2] = {0u, 0u}, eB[2] = {0u, 0u};
-      bool eok[2] = {false, false};
-      auto write_out = [&](int h, u32 t) {
-        if constexpr (OUT) {
-          const u64 rh = ((u64)a.out_first + first + t) * 2 + h;
-          u32x4* dst = (u32x4*)(a.planes_out + (((u64)kt * (u64)a.rows_out + rh) * (u64)a.go) * 256u) + lane;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (j < a.go) {
-              u32x4 v = {0u, 0u, 0u, 0u};
-              if (4 * j < L) v = u32x4{C[h][(4 * j) % L], (4 * j + 1 < L) ? C[h][(4 * j + 1) % L] : 0u,
-                                       (4 * j + 2 < L) ? C[h][(4 * j + 2) % L] : 0u, (4 * j + 3 < L) ? C[h][(4 * j + 3) % L] : 0u};
-              dst[j * 64] = v;
-            }
-          }
-        }
-      };
-      auto compute = [&](int h, u32 t, const u32 (&y)[8], const u32 (&Z)[LZ]) {
-        const u32 r0 = rdlane(infov[h], t);
-        const u32 len = r0 & kLinfoLenMask;
-        const bool overlap = (r0 & 1u) != 0u;
-        if (!overlap && len == (r0 >> 28)) {   // an empty delta list (the gene sits in the other half): the half is paths0's
-#pragma unroll
-          for (int l = 0; l < L; l++) C[h][l] = B[h][l];
-          write_out(h, t);
-          return;
-        }
-        u32 S[L];
-        {
-          u32 S4[4];
-          sum8(y, S4);
-#pragma unroll
-          for (int l = 0; l < L; l++) S[l] = (l < 4) ? S4[l < 4 ? l : 0] : 0u;
-        }
-        if (len > 8u) {   // long list (rare): further blocks of 8 entries
-          const u32 GCRE_CONSTANT* more = (const u32 GCRE_CONSTANT*)(a.dover + rdlane(lovv[h], t));
-          for (u32 p = 0u; p + 8u < len; p += 8u) {
-            const u32x8 o8 = *(const u32x8 GCRE_CONSTANT*)(more + p);
-            u32 yy[8], s4[4];
-#pragma unroll
-            for (int j = 0; j < 8; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, o8[j], 0);
-            sum8(yy, s4);
-            u32 cy = 0u;
-#pragma unroll
-            for (int l = 0; l < L; l++) {
-              const u32 sv = S[l];
-              const u32 add = (l < 4) ? s4[l < 4 ? l : 0] : 0u;
-              S[l] = xor3(sv, add, cy);
-              cy = majority(sv, add, cy);
-            }
-          }
-        }
-        if (overlap) {   // C = B + Nz - S
-          u32 cy = 0u, bw = 0u;
-#pragma unroll
-          for (int l = 0; l < L; l++) {
-            const u32 zl = (l < LZ) ? Z[l < LZ ? l : 0] : 0u;
-            const u32 s1_ = xor3(B[h][l], zl, cy);
-            cy = majority(B[h][l], zl, cy);
-            C[h][l] = xor3(s1_, S[l], bw);
-            bw = borrow3(s1_, S[l], bw);
-          }
-        } else {         // C = B + S
-          u32 cy = 0u;
-#pragma unroll
-          for (int l = 0; l < L; l++) {
-            C[h][l] = xor3(B[h][l], S[l], cy);
-            cy = majority(B[h][l], S[l], cy);
-          }
-        }
-        write_out(h, t);
-      };
-      u32 yA[8], yB[8], ZA[LZ], ZB[LZ];
-#pragma unroll
-      for (int l = 0; l < LZ; l++) ZA[l] = ZB[l] = 0u;
-      u32x8 oA = slots[0], oB = slots[1];
-      issue(0, 0u, oA, yA, ZA);
-      for (u32 t = 0; t < npaths; t++) {
-        issue(1, t, oB, yB, ZB);
-        oA = slots[at(t + 1u) * 2u];
-        compute(0, t, yA, ZA);
-        issue(0, at(t + 1u), oA, yA, ZA);
-        oB = slots[at(t + 1u) * 2u + 1u];
-        compute(1, t, yB, ZB);
-        // ---- a permutation is safe when (F <= ha and G <= hb) or (F <= hb and G <= ha): ha + hb <= theta ----
-        u32 pa, pb, na, nb_;
-        {
-          const u32 i0 = rdlane(infov[0], t), i1 = rdlane(infov[1], t);
-          const bool e0 = !(i0 & 1u) && (i0 & kLinfoLenMask) == (i0 >> 28), e1 = !(i1 & 1u) && (i1 & kLinfoLenMask) == (i1 >> 28);
-          if (e0) {
-            if (!eok[0]) { eA[0] = outside(B[0], rdlane(lha[0], t)); eB[0] = outside(B[0], rdlane(lhb[0], t)); eok[0] = true; }
-            pa = eA[0]; pb = eB[0];
-          } else {
-            pa = outside(C[0], rdlane(lha[0], t)); pb = outside(C[0], rdlane(lhb[0], t));
-          }
-          if (e1) {
-            if (!eok[1]) { eA[1] = outside(B[1], rdlane(lha[1], t)); eB[1] = outside(B[1], rdlane(lhb[1], t)); eok[1] = true; }
-            na = eA[1]; nb_ = eB[1];
-          } else {
-            na = outside(C[1], rdlane(lha[1], t)); nb_ = outside(C[1], rdlane(lhb[1], t));
-          }
-        }
-        u32 m = (pa | nb_) & (pb | na) & valid;
-        if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;
-        n_slow++;
-        const u32 dp = sp_diag_offset(rdlane(totv[0], t)), dn = sp_diag_offset(rdlane(totv[1], t));
-        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {   // one permutation per lane and round
-          if (lq_n + 64u > kLqCap) lq_drain();
-          const bool has = m != 0u;
-          const u32 bb = has ? (u32)__builtin_ctz(m) : 0u;
-          m &= m - 1u;
-          u32 ca = 0u, cb = 0u;
-#pragma unroll
-          for (int l = 0; l < L; l++) {
-            ca |= ((C[0][l] >> bb) & 1u) << l;
-            cb |= ((C[1][l] >> bb) & 1u) << l;
-          }
-          const u64 hm = __builtin_amdgcn_ballot_w64(has);
-          const u32 pos = lq_n + __builtin_amdgcn_mbcnt_hi((u32)(hm >> 32), __builtin_amdgcn_mbcnt_lo((u32)hm, 0u));
-          if (has) {
-            lq[0][pos] = dp + ca;
-            lq[1][pos] = dn + cb;
-            lq[2][pos] = bb * 64u + (u32)lane;
-          }
-          lq_n += (u32)__builtin_popcountll(hm);
-        }
-        dirty = true;
-      }
-    }
-  }
-  flush_tile();
-  if (a.stats && lane == 0 && n_slow) atomicAdd(a.stats, n_slow);
-}
-
 // method 2 runs the general kernel; method 1 the specialised one: L from the largest carrier total, GZ = plane groups of
 // the added rows that can be non-zero (<= L/4), OUT = planes of the joined paths wanted
 #define GCRE_IE_M2(EXPR)                    \
   if (planes <= 8) { EXPR(2, 8); }          \
   else if (planes <= 12) { EXPR(2, 12); }   \
   else { EXPR(2, 16); }
-
-// pruned signed-method kernel: counter planes of the joined paths x plane groups of the added rows
-#define GCRE_IE_M2P(EXPR)                                                                  \
-  if (planes <= 8) { EXPR(8, 2); }                                                         \
-  else if (planes <= 10) { if (a.gz <= 2) { EXPR(10, 2); } else { EXPR(10, 3); } }         \
-  else if (planes <= 12) { if (a.gz <= 2) { EXPR(12, 2); } else { EXPR(12, 3); } }         \
-  else { if (a.gz <= 2) { EXPR(16, 2); } else { EXPR(16, 4); } }
 
 #define GCRE_IE_M1_OR(EXPR, LL, GG)                                                  \
   if (out) { if (rec) { EXPR(LL, GG, true, true); } else { EXPR(LL, GG, true, false); } }   \
@@ -1356,10 +994,7 @@ hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general,
     GCRE_IE_M1(GCRE_LAUNCH)
 #undef GCRE_LAUNCH
   } else if (method == 2 && !general) {
-    const bool out = a.planes_out != nullptr;
-#define GCRE_LAUNCH2(LL, GG) if (out) hipLaunchKernelGGL((k_null_ie_m2<LL, GG, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((k_null_ie_m2<LL, GG, false>), grid, block, 0, stream, a)
-    GCRE_IE_M2P(GCRE_LAUNCH2)
-#undef GCRE_LAUNCH2
+    return launch_null_ie_m2(a, planes, stream);
   } else {
 #define GCRE_LAUNCH(MM, LL) hipLaunchKernelGGL((k_null_ie<MM, LL>), grid, block, 0, stream, a)
     GCRE_IE_GEN(GCRE_LAUNCH)
@@ -1376,10 +1011,7 @@ int ie_max_waves_per_cu(int method, int planes, int gz, bool out, bool rec) {
     GCRE_IE_M1(GCRE_OCC)
 #undef GCRE_OCC
   } else {
-    struct { int gz; } a{gz};
-#define GCRE_OCC2(LL, GG) e = out ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m2<LL, GG, true>, 64 * kIeWaves, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_null_ie_m2<LL, GG, false>, 64 * kIeWaves, 0)
-    GCRE_IE_M2P(GCRE_OCC2)
-#undef GCRE_OCC2
+    return ie2_max_waves_per_cu(planes, gz, out, rec);
   }
   if (e != hipSuccess || blocks < 1) blocks = 1;
   return blocks * kIeWaves;

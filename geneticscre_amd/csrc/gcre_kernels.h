@@ -104,8 +104,9 @@ struct IeArgs {
   const uint32_t* planes0;   // count planes of paths0 [tile][row*M+h][g0][64][4], or nullptr: stream loff0/lidx0
   const uint32_t* planesz;   // count planes of the reduced operand [tile][row*M+h][gz][64][4] (mode-1 paths)
   uint32_t rows0, rowsz, rows_out;   // row-halves (rows * M) of the three plane arrays
-  // method 1, paths0 without stored planes but with the recipe of the join that produced it (rec_slot != nullptr): row r of
-  // paths0 = row rec_row0[r] of set A | row rec_rowz[r] of set Z, list info / slot / overflow as that join's inspector left them
+  // paths0 without stored planes but with the recipe of the join that produced it (rec_slot != nullptr): row r of
+  // paths0 = row rec_row0[r] of set A | row rec_rowz[r] of set Z (bit 31: halves swapped), list info / slot / overflow per
+  // list (row * M + half) as that join's inspector left them; rec_rows_a / rec_rows_z = row-halves of A / Z
   const uint32_t* rec_row0;
   const uint32_t* rec_rowz;
   const uint32_t* rec_linfo;
@@ -157,6 +158,10 @@ hipError_t launch_fill_rec_segs(const SparseSeg* segs, int64_t nsegs, const uint
                                 uint32_t* out, hipStream_t stream);
 hipError_t launch_null_ie(const IeArgs& a, int method, int planes, bool general, hipStream_t stream);
 int ie_max_waves_per_cu(int method, int planes, int gz, bool out, bool rec);
+// the signed method's pruned kernel (gcre_ie2.hip); rec_rows_a / rec_rows_z count row-halves
+hipError_t launch_null_ie_m2(const IeArgs& a, int planes, hipStream_t stream);
+int ie2_max_waves_per_cu(int planes, int gz, bool out, bool rec);
+int ie2_steps();   // steps of the staircase cover of F + G <= theta (GCRE_M2_STEPS)
 hipError_t launch_build_planes(const uint32_t* mt, uint32_t mt_rows, int nkt, const uint64_t* loff, const uint32_t* lidx,
                                int64_t nrowhalves, int groups, uint32_t* planes, hipStream_t stream);
 hipError_t launch_build_ladder(const float* t32, int TD, uint32_t* ladder, hipStream_t stream);
