@@ -230,6 +230,7 @@ struct gcre_ctx {
   uint32_t* d_max_tot = nullptr;     // 8 words: largest carrier total of the chunk, "reduced operand is wrong", overlap lists,
                                      // looked-up tiles, entries reserved in the long-list area
   uint32_t* d_ladder = nullptr;      // method 1: pruning ladder of the null table [kLadderLevels][TD]
+  uint32_t g00_rows = 0xffffffffu;   // method 2: vtmax[0][0] in ladder rows, rounded up (IeArgs::g00_rows)
   int null_kernel = 0;               // 0 auto, 1 dense, 2 sparse, 3 ie (GCRE_NULL_KERNEL)
   int sparse_waves_per_cu = 32;
   int ie_prune = 1;                  // GCRE_IE_PRUNE=0 looks every count up (diagnostics)
@@ -1327,6 +1328,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     };
     auto prepare_z = [&]() -> int {
       red = hinted ? u.red : jp.p1;
+      // a kept set read as the added rows (level 5 adds rows of paths2) without planes of its own: they are rebuilt from
+      // its bit lists now, and the join that writes its rows leaves them next time
+      if (!planes_current(c, red) && red->rec) red->planes_wanted = true;
       if (int rc = ensure_lists(c, red)) return rc;
       if (int rc = ensure_planes(c, red)) return rc;
       have_pz = planes_current(c, red);
@@ -1727,6 +1731,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ia.ladder = c->d_ladder;
           ia.ladder_stride = g.TD;
           ia.lad_mode = !scored ? 1 : (c->ie_prune ? 0 : 2);
+          ia.g00_rows = c->g00_rows;
           ia.null_bits = w_null;
           ia.planes_out = res_planes ? jp.res->d_planes : nullptr;
           ia.go = res_planes ? jp.res->plane_groups : 0;
@@ -1859,7 +1864,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             HIP_TRY(c, hipMemcpyAsync(tmv, d_timing, 64, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
             const double waves = 8.0 * ia.waves_per_xcd;
-            if (ie_quad_ran)
+            if (g.method == 2)
+              std::fprintf(stderr, "[ie2 classes] paths %lld x %d tiles: path-tiles with the other half empty %llu, one test %llu, all steps %llu, both halves %llu; "
+                           "lists of 5-8 rows %llu, long lists %llu; permutations looked up %llu\n", (long long)n, ia.nkt, (unsigned long long)tmv[0],
+                           (unsigned long long)tmv[1], (unsigned long long)tmv[2], (unsigned long long)tmv[3], (unsigned long long)tmv[4],
+                           (unsigned long long)tmv[6], (unsigned long long)tmv[5]);
+            else if (ie_quad_ran)
               std::fprintf(stderr, "[ieq timing] paths %lld waves %.0f quads/wave %.0f: per-wave Mcycles header+loads %.2f base counters %.2f intervals %.2f filter pass %.2f exact pass %.2f exchange %.2f total %.2f\n",
                            (long long)n, waves, tmv[7] / waves, tmv[0] / waves / 1e6, tmv[1] / waves / 1e6, tmv[2] / waves / 1e6, tmv[3] / waves / 1e6,
                            tmv[4] / waves / 1e6, tmv[5] / waves / 1e6, tmv[6] / waves / 1e6);
@@ -2313,6 +2323,16 @@ int gcre_set_value_table(gcre_ctx* c, const double* table, int nrow, int ncol, i
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d_raw);
+  c->g00_rows = 0xffffffffu;
+  if (e == hipSuccess && g.method == 2) {
+    // what an empty half adds to a path's null score: vtmax[0][0], as the device table holds it, rounded UP to ladder rows
+    double g00 = 0;
+    e = hipMemcpy(&g00, c->d_dmax, 8, hipMemcpyDeviceToHost);
+    if (!(g00 != g00)) {
+      const double x = g00 > 0 ? std::ceil(g00 * (double)(2 * kLadderPerUnit)) : 0.0;   // (times 16: exact)
+      if (x < 1e9) c->g00_rows = (uint32_t)x;
+    }
+  }
   if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("set_value_table: ") + hipGetErrorString(e));
   c->have_table = true;
   c->obs_epoch++;
@@ -2942,6 +2962,7 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
       // the sequence is known here: when level 3's rows are too many to leave with count planes they leave with a recipe
       // whose operand is this set -- which then must not be recipe-only itself (it would be rebuilt from bit lists)
       if (L >= 4 && plane_bytes(c, total_paths(in->level[3]), 2) > c->planes_out_max) paths2->planes_wanted = true;
+      if (L >= 5) paths2->planes_wanted = true;   // level 5 adds rows of this set: their planes are read per joined path
       // the reference reads data_idx2 from r_data_inds3 (wrapper.cpp:207); R passes identical vectors
       if (!input_l2) temps.push_back(input_l2 = gcre_pathset_select(c, parsed1, in->data_inds[3], in->n_data_inds[3]));
       gcre_pathset* const input = input_l2;

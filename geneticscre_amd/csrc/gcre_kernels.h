@@ -141,6 +141,8 @@ struct IeArgs {
   int nkt, waves_per_xcd, K;
   int g0, gz, go;            // plane groups (4 planes each) of the three plane arrays
   int lad_mode;              // method-1 kernel: 0 thresholds from the running maxima, 1 look nothing up, 2 look everything up
+  uint32_t g00_rows;         // signed kernel: vtmax[0][0] <= g00_rows / (2 kLadderPerUnit), what an EMPTY half contributes to a
+                             // path's null score (0 for the hypergeometric table); 0xffffffff: not bounded (NaN)
   int ladder_stride;         // = number of table diagonals
   uint32_t mt_rows, zoff;
   // quad form of the pruned method-1 kernel (gcre_ieq.hip): entry = first segment | (segments - 1) << 30, up to four
