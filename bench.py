@@ -380,6 +380,79 @@ def sensitivity(prob, masks, cfg, seed, device, rates=(0.01, 0.025, 0.05), steps
     return out
 
 
+def result_digest(names, results) -> str:
+    """SHA-256 over every level's scores, ids, counts and null maxima: equal digests = bit-identical results."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in names:
+        r = results[name]
+        for arr in (r.scores, r.src, r.trg, r.cases, r.ctrls, r.null):
+            h.update(np.ascontiguousarray(arr).tobytes())
+    return h.hexdigest()
+
+
+def other_configs(args, device, steps=2):
+    """The other single-GPU BASELINE configs, measured by the same process right after the headline (one warm-up + `steps`
+    timed passes each, inputs resident): configs[1], configs[3] on ONE GPU, the signed method on configs[2]'s geometry and
+    configs[4].  Parity-test cases with a clock on them, never part of `value`; each carries the digest of its results."""
+    import torch
+    from geneticscre_amd import api
+    runs = [("subgraph", {}, "BASELINE configs[1]"),
+            ("roofline", {"method": "method2"}, "configs[2] geometry, method2 (the reference's default method, test/harness.cpp:46)"),
+            ("sharded", {}, "BASELINE configs[3] on ONE GPU (the geometry BASELINE names for eight)"),
+            ("signed", {}, "BASELINE configs[4] on ONE GPU, synthetic network of 60,000 relations (see `network_note`)")]
+    out = {}
+    for name, override, what in runs:
+        key = name if not override else f"{name}_{override['method']}"
+        t_all = time.perf_counter()
+        try:
+            cfg = dict(CONFIGS[name])
+            cfg.update(override)
+            prob, masks = build_inputs(cfg, args.seed, args.top_k)
+            plan = api.ResidentPlan(prob, device=device, packed_masks=masks, mask_seed=args.seed if masks is None else None)
+            try:
+                plan.set_window(plan.planned_window())
+                plan.run()
+                torch.cuda.synchronize()
+                acc = {}
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    last = plan.run()
+                    for k, v in plan.last_profile.items():
+                        acc[k] = acc.get(k, 0) + v
+                torch.cuda.synchronize()
+                t = (time.perf_counter() - t0) / steps
+                null_s = acc.get("null_kernel_ms", 0.0) / 1e3
+                ach = acc.get("null_alg_bytes", 0.0) / 1e9 / null_s if null_s > 0 else 0.0
+                K = prob.iterations
+                out[key] = {
+                    "what": what, "value": plan.total_scores() / t, "unit": "scores/s", "ms_per_step": t * 1e3, "steps": steps,
+                    "workload": f"{cfg['genes']} genes / {cfg['edges']} relations, {prob.n_cases}+{prob.n_ctrls} patients, {K} permutations, "
+                                f"path length {prob.path_length}, {prob.method}",
+                    "paths_per_level": {k: plan.uids[k].total_paths for k in plan.names},
+                    "permutation_windows": len(plan.windows()),
+                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "avg_null_ms_per_join": null_s * 1e3 / max(int(acc.get("null_kernel_launches", 0)), 1)},
+                    "phases_ms_per_step": {k: acc.get(k, 0.0) / steps for k in ("null_kernel_ms", "stats_kernel_ms", "total_ms")},
+                    "lookup_tiles_per_step": int(acc.get("ie_lookup_tiles", 0)) // steps,
+                    "masks": "uploaded" if masks is not None else "drawn on the device (gcre_generate_perm_masks)",
+                    "table": "hypergeometric (numpy restatement of getValuesTable)" if masks is not None
+                             else ("hypergeometric (native gcre_values_table: R's dhyper restated, unpinned against R; summation order: "
+                                   + ("R's index order" if api.values_table_exact_order(prob.n_cases, prob.n_ctrls) else "sorted prefix sum") + ")"),
+                    "result_sha256": result_digest(plan.names, last),
+                }
+                if name == "signed":
+                    out[key]["network_note"] = ("60,000 relations give 2.0 M level-5 paths; a network of 200,000 relations (the other "
+                                                "configs') has ~3e8 level-5 paths and has not been run on one GPU")
+            finally:
+                plan.close()
+            del prob, masks, plan
+        except Exception as e:   # reported, never required
+            out[key] = {"what": what, "error": repr(e)}
+        out[key]["wall_s"] = time.perf_counter() - t_all
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -401,6 +474,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the 1 % / 2.5 % / 5 % carrier-rate passes")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the extra passes with kept inspections")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the passes over the other single-GPU configs (configs[1], [3], [4], method2) after the headline")
     ap.add_argument("--no-one-gpu-reference", action="store_true",
                     help="N > 1: skip the two passes of the whole workload on rank 0's GPU alone")
     ap.add_argument("--no-exchange", action="store_true", help="N > 1: ranks do not share their running maxima during a join")
@@ -657,15 +732,15 @@ def main():
             line["cpu_baseline"]["six_joins"] = six_join_baseline(cfg, args.seed, args.top_k, line["cpu_baseline"])
         except Exception as e:   # the baseline is reported, never required
             line["cpu_baseline"] = {"error": repr(e)}
-    if rank == 0 and os.environ.get("GCRE_BENCH_DUMP"):
-        # digest of the last step's results, for comparing runs with different rank counts
-        import hashlib
-        h = hashlib.sha256()
-        for name in plan.names:
-            r = last[name]
-            for arr in (r.scores, r.src, r.trg, r.cases, r.ctrls, r.null):
-                h.update(np.ascontiguousarray(arr).tobytes())
-        line["result_sha256"] = h.hexdigest()
+    if rank == 0:
+        # digest of the last step's results: equal for every rank count, kernel form and tuning knob
+        line["result_sha256"] = result_digest(plan.names, last)
+        lib = api.load_library()
+        line["library"] = {"path": os.path.relpath(os.environ.get("GCRE_LIB") or api.lib_path(), ROOT),
+                           "abi": int(lib.gcre_abi_version()), "build_flags": lib.gcre_build_flags().decode()}
+    if rank == 0 and world == 1 and default_run and args.config == "roofline" and not args.no_other_configs:
+        plan.close()          # the headline's sets and planes leave the device first
+        line["other_configs"] = other_configs(args, local_rank)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -19,6 +19,7 @@ from . import build as _build
 _LIB = None
 
 GCRE_OK, GCRE_ERR_ASSERT, GCRE_ERR_RANGE, GCRE_ERR_DEVICE, GCRE_ERR_ARG = 0, -1, -2, -3, -4
+EXPECTED_ABI = 4   # GCRE_ABI_VERSION of include/gcre_hip.h this mirror was written against
 
 
 class GcreError(RuntimeError):
@@ -90,7 +91,7 @@ EXPORTS = [
     "gcre_pathset_from_dense", "gcre_pathset_from_words", "gcre_pathset_select", "gcre_pathset_size",
     "gcre_pathset_read", "gcre_pathset_free", "gcre_join", "gcre_result_free", "gcre_uids_create",
     "gcre_uids_total_paths", "gcre_uids_free", "gcre_join_uids", "gcre_get_profile",
-    "gcre_process_paths", "gcre_resolve_count_locs", "gcre_build_levels", "gcre_levels_free", "gcre_values_table",
+    "gcre_process_paths", "gcre_resolve_count_locs", "gcre_build_levels", "gcre_levels_free", "gcre_values_table", "gcre_values_table_exact_order",
     "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask", "gcre_uids_set_reduced",
     "gcre_set_perm_window", "gcre_plan_perm_window", "gcre_process_paths_devices",
     "gcre_set_inspect_cache", "gcre_drop_inspections", "gcre_build_flags", "gcre_device_count",
@@ -121,6 +122,19 @@ def load_library():
     lib.gcre_last_error.argtypes = [V]
     lib.gcre_abi_version.restype = I
     lib.gcre_build_flags.restype = ctypes.c_char_p
+    if os.environ.get("GCRE_LIB"):
+        # a variant library skips build()'s staleness and diagnostics checks: make up for them here
+        if not hasattr(lib, "gcre_abi_version") or lib.gcre_abi_version() != EXPECTED_ABI:
+            raise GcreError(f"GCRE_LIB={path}: ABI {lib.gcre_abi_version() if hasattr(lib, 'gcre_abi_version') else '?'}, "
+                            f"this tree expects {EXPECTED_ABI} (rebuild the variant: tools/build_variant.py)")
+        flags = lib.gcre_build_flags().decode()
+        diag = [f for f in flags.split() if f.startswith("-D") and (f[2:].split("=")[0] in _build.DIAG_DEFINES or "ZHACK" in f or
+                                                                      (f[2:].startswith("GCRE_") and "_NO" in f[2:]))]
+        if diag and os.environ.get("GCRE_ALLOW_DIAG_BUILD") != "1":
+            raise GcreError(f"GCRE_LIB={path} is a diagnostics build ({' '.join(diag)}): its results are wrong by design; "
+                            "set GCRE_ALLOW_DIAG_BUILD=1 for a timing experiment")
+        import sys
+        print(f"[gcre] GCRE_LIB: using variant library {path} (build flags: {flags or 'none'})", file=sys.stderr)
     lib.gcre_set_top_k.argtypes = [V, I]
     lib.gcre_width_ul.argtypes = [V]
     lib.gcre_vlen.argtypes = [V]
@@ -158,6 +172,7 @@ def load_library():
     lib.gcre_levels_free.argtypes = [ctypes.POINTER(gcre_levels)]
     lib.gcre_levels_free.restype = None
     lib.gcre_values_table.argtypes = [I, I, P]
+    lib.gcre_values_table_exact_order.argtypes = [I, I]
     lib.gcre_generate_perm_masks.argtypes = [V, ctypes.c_uint64, P, I]
     lib.gcre_mix64.restype = ctypes.c_uint64
     lib.gcre_mix64.argtypes = [ctypes.c_uint64]
@@ -511,6 +526,12 @@ def values_table(n_cases: int, n_ctrls: int) -> np.ndarray:
     if rc != GCRE_OK:
         raise ValueError("bad table dimensions")
     return out
+
+
+def values_table_exact_order(n_cases: int, n_ctrls: int) -> bool:
+    """True: ``values_table`` sums every cell in R's index order at this size; False: the sorted prefix sum of very large
+    cohorts (the last bit of a cell in a hundred can differ).  Recorded with fixtures and bench lines."""
+    return bool(load_library().gcre_values_table_exact_order(int(n_cases), int(n_ctrls)))
 
 
 def _pp_input(problem, keep):

@@ -320,6 +320,26 @@ void gcre_levels_free(gcre_levels* lv) {
   std::memset(lv, 0, sizeof *lv);
 }
 
+static double vt_work(int n_cases, int n_ctrls) {
+  const int n = n_cases + n_ctrls;
+  double work_est = 0;
+  for (int i = 0; i <= n; i++) {
+    const double m = (double)(std::min(i, n_cases) - std::max(0, i - n_ctrls) + 1);
+    work_est += m * m;
+  }
+  return work_est;
+}
+static double vt_exact_work_limit() {
+  double exact_work = 2.5e11;
+  if (const char* e = std::getenv("GCRE_VT_EXACT_WORK")) exact_work = std::atof(e);   // tests: 0 forces the prefix-sum form
+  return exact_work;
+}
+
+int gcre_values_table_exact_order(int n_cases, int n_ctrls) {
+  if (n_cases < 0 || n_ctrls < 0) return GCRE_ERR_ARG;
+  return vt_work(n_cases, n_ctrls) <= vt_exact_work_limit() ? 1 : 0;
+}
+
 int gcre_values_table(int n_cases, int n_ctrls, double* out) {
   // getValuesTable (Utils.R:137-159): out[x][i-x] = -log(two-sided hypergeometric p of x cases among i carriers);
   // two-sided p = sum(prob[prob <= prob_x]) with R's EXACT `<=` on the doubles stats::dhyper returns (:153);
@@ -335,14 +355,7 @@ int gcre_values_table(int n_cases, int n_ctrls, double* out) {
   if (n_cases < 0 || n_ctrls < 0 || !out) return GCRE_ERR_ARG;
   const int n = n_cases + n_ctrls;
   const size_t cols = (size_t)n_ctrls + 1;
-  double work_est = 0;
-  for (int i = 0; i <= n; i++) {
-    const double m = (double)(std::min(i, n_cases) - std::max(0, i - n_ctrls) + 1);
-    work_est += m * m;
-  }
-  double exact_work = 2.5e11;
-  if (const char* e = std::getenv("GCRE_VT_EXACT_WORK")) exact_work = std::atof(e);   // tests: 0 forces the prefix-sum form
-  const bool exact_order = work_est <= exact_work;
+  const bool exact_order = vt_work(n_cases, n_ctrls) <= vt_exact_work_limit();   // (gcre_values_table_exact_order says which)
   int T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (n < 256) T = 1;
   std::vector<double> tmax((size_t)T, -std::numeric_limits<double>::infinity());

@@ -158,7 +158,8 @@ struct ExchangeHub {
   std::condition_variable cv;
   int arrived = 0;
   uint64_t gen = 0;
-  bool failed = false;
+  bool failed = false, timed_out = false;
+  double timeout_s = 300.0;
   std::vector<float> acc, result;
   uint64_t round_tag = 0;
   // tag = (level, permutation window, ordinal of the exchange inside the join): every device of a round must bring the same
@@ -179,8 +180,16 @@ struct ExchangeHub {
       gen++;
       cv.notify_all();
     } else {
+      // a device that never arrives (its thread died, it took another road through the join) must not hold the others for
+      // ever: past the deadline the round -- and with it the call -- fails (GCRE_HUB_TIMEOUT_S, default 300 s: a join of
+      // configs[4] on a shared GPU takes seconds)
       const uint64_t g = gen;
-      cv.wait(lk, [&] { return gen != g || failed; });
+      if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return gen != g || failed; })) {
+        failed = true;
+        timed_out = true;
+        cv.notify_all();
+        return 1;
+      }
       if (gen == g) return 1;   // somebody failed before this round completed
     }
     mine = result;
@@ -792,16 +801,16 @@ void build_segments_host(const gcre_uids& u, int64_t first, int64_t count, int64
   *nscored_out = (int64_t)n_scored;
 }
 
-// quads of a segment table (gcre_ieq.hip): runs of up to four consecutive segments with the same first joined row and
+// quads of a segment table (gcre_ieq.hip): runs of up to ieq_quad_segs() consecutive segments with the same first joined row and
 // length, none straddling n_warm or nscored.  Host only.
 void build_quads_host(const gcre_uids& u, const std::vector<SparseSeg>& segs, int64_t first, int64_t nscored, int64_t n_warm,
                       std::vector<uint32_t>& quads, int64_t* quad_begin_out) {
   const auto& pi = u.h_path_idx;
   const int64_t n = (int64_t)segs.size();
   quads.clear();
-  quads.reserve((size_t)n / 3 + 16);
   int64_t quad_begin = -1;
   const int64_t qmax = ieq_quad_segs();
+  quads.reserve((size_t)n / (size_t)std::max<int64_t>(1, (qmax + 1) / 2) + 16);
   auto key_of = [&](const SparseSeg& x) { return u.h_location[x.row0] + ((int64_t)x.first + first - pi[x.row0]); };
   int64_t i = 0;
   while (i < n) {
@@ -877,7 +886,7 @@ int sparse_segments(gcre_ctx* c, const gcre_uids& u, int64_t first, int64_t coun
   return GCRE_OK;
 }
 
-// Quad table of a cached segment table (see gcre_ieq.hip): greedy runs of up to four consecutive segments with the same
+// Quad table of a cached segment table (see gcre_ieq.hip): greedy runs of up to ieq_quad_segs() consecutive segments with the same
 // first joined paths1 row and the same length -- they join the same rows --, cut at `n_warm` (the pruned launch starts
 // there) and at the end of the scored segments.  quad_begin = the first quad of the pruned launch.
 int ensure_quads(gcre_ctx* c, const gcre_uids& u, gcre_uids::SegCache& sc, int64_t n_warm) {
@@ -1802,7 +1811,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             if (g.method == 1 && c->d_ladder && c->ie_quad && !ia.planes_out && seg_entry &&
                 ensure_quads(c, u, *seg_entry, ia.seg_begin) == GCRE_OK) {
               const int64_t nq = seg_entry->nquads - seg_entry->quad_begin;
-              quad = nq > 0 && ((ia.seg_end - ia.seg_begin) * 2 >= nq * 3 || c->ie_quad == 2);   // 1.5 segments per quad on average
+              // worth it from 1 + (qmax - 1) / 4 segments per quad on average: 1.25 with two segments per quad (a quad of one
+              // segment does what k_null_ie_m1 does with a longer prologue); the 1.5 of the four-segment form could never be
+              // reached by joins that average 1.3-1.5
+              const int64_t qmax = ieq_quad_segs();
+              quad = nq > 0 && ((ia.seg_end - ia.seg_begin) * 4 >= nq * (4 + (qmax - 1)) || c->ie_quad == 2);
               if (std::getenv("GCRE_HOST_TIMING"))
                 std::fprintf(stderr, "[host] quads: %lld segments in %lld quads (%.2f per quad), %lld joined paths, quad form %s\n",
                              (long long)(ia.seg_end - ia.seg_begin), (long long)nq, (double)(ia.seg_end - ia.seg_begin) / (double)std::max<int64_t>(nq, 1),
@@ -3074,6 +3087,7 @@ int gcre_process_paths_devices(int method, int n_cases, int n_ctrls, int iterati
   std::vector<int> rcs((size_t)N, GCRE_OK);
   ExchangeHub hub;   // where the device threads MAX-merge their running maxima during the large joins
   hub.n = N;
+  if (const char* e = std::getenv("GCRE_HUB_TIMEOUT_S")) hub.timeout_s = std::max(0.01, std::atof(e));
   if (rc == GCRE_OK) {
     auto work = [&](int r) {
       gcre_pp_input mine = *in;
@@ -3092,7 +3106,8 @@ int gcre_process_paths_devices(int method, int n_cases, int n_ctrls, int iterati
     for (int r = 0; r < N; r++)
       if (rcs[(size_t)r] != GCRE_OK && rc == GCRE_OK) {
         rc = rcs[(size_t)r];
-        say("device " + std::to_string(dev[(size_t)r]) + ": " + gcre_last_error(ctx[(size_t)r]));
+        say("device " + std::to_string(dev[(size_t)r]) + ": " + gcre_last_error(ctx[(size_t)r]) +
+            (hub.timed_out ? " (a device waited longer than GCRE_HUB_TIMEOUT_S for the others at a threshold exchange)" : ""));
       }
   }
   if (rc == GCRE_OK) {

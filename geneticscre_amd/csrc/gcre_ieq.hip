@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
     u32 qe_n = 0u;
     bool have_next = false;
     for (u32 qi = q_lo; qi < q_hi; qi++) {
-      // ---- the quad: up to four consecutive segments of the table, same added rows, same length ----
+      // ---- the quad: up to kQSegs consecutive segments of the table, same added rows, same length ----
       GCRE_QT(t0);
       u32 hdr[kQSegs];
       u32 qe;
@@ -372,6 +372,9 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(G
       // marked, one bit per path in a scalar mask per segment: nothing in this loop waits for anything but the planes.
       u64 todo[kQSegs] = {};
       auto filter_f = [&](int g, u32 t, const u32 (&Bg)[L], const u32 (&Z)[LZ]) {
+        // rows of another shard (the ladder's all-inside row): nothing of theirs is scored, so nothing is examined -- neither
+        // a carry out of the top plane nor a delta list may send such a path to the second look or the exact pass
+        if (lad_row == lad_keep) return;
         const u32 lf = rdlane(lfv[g], t);   // hi << 16 | lo + ov
         u32 cy = 0u, blo = 0u, bhi = 0u;
 #pragma unroll

@@ -263,6 +263,11 @@ void gcre_levels_free(gcre_levels* levels);
 /* getValuesTable (R/Utils.R:137-159): out[(n_cases+1) x (n_ctrls+1)] row-major, -log two-sided hypergeometric p.
  * Parity with R's stats::dhyper is unpinned (no R in the build image); the scorer treats the table as opaque input. */
 int gcre_values_table(int n_cases, int n_ctrls, double* out);
+/* Which summation order gcre_values_table uses at this size: 1 = R's index order for every cell (the table R builds wherever
+ * libm agrees), 0 = the sorted prefix sum of very large cohorts (past 2.5e11 inner steps, ~14,000 patients: same outcomes, same
+ * accumulator, the rounded double can move in its last place).  Fixtures record it next to their input digest.  The test-only
+ * GCRE_VT_EXACT_WORK environment variable moves the threshold for both functions alike. */
+int gcre_values_table_exact_order(int n_cases, int n_ctrls);
 
 /* getRandIndicesMat + getCaseORControl + setPermutedCases (R/Utils.R:22-46, 246-262; src/join_base.cpp:85-125) fused
  * on the device: permutation r = a uniformly random relabelling that keeps n_cases cases (inside every stratum when

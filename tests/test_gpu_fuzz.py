@@ -35,6 +35,20 @@ KNOBS = {
 }
 
 
+def entered(test: str, case: int) -> None:
+    """`-x -q` shows dots only: the case in flight goes to stderr and to a progress file that survives a run cut off by the
+    box's time limit (GCRE_FUZZ_LOG, default gpurun_out/fuzz_progress.log when that directory exists)."""
+    line = f"[fuzz] {test} case {case} (GCRE_FUZZ_BASE={BASE})"
+    import sys
+    print(line, file=sys.stderr, flush=True)
+    path = os.environ.get("GCRE_FUZZ_LOG")
+    if path is None and os.path.isdir("gpurun_out"):
+        path = os.path.join("gpurun_out", "fuzz_progress.log")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")
+
+
 def value_table(kind: str, n_cases: int, n_ctrls: int, seed: int):
     """None = the hypergeometric table; otherwise an arbitrary one (the pruning must be exact for any table)."""
     if kind == "hyper":
@@ -97,6 +111,7 @@ def draw(case: int):
 
 @pytest.mark.parametrize("case", range(N_CASES))
 def test_random_problem_matches_oracle(case, monkeypatch):
+    entered("problem_matches_oracle", BASE + case)
     cfg, env = draw(BASE + case)
     for k, v in env.items():
         if v:
@@ -114,6 +129,7 @@ def test_random_problem_matches_oracle(case, monkeypatch):
 def test_random_sharded_plan_matches_oracle(case, monkeypatch):
     """The same draw through ResidentPlan, sharded over 2..5 ranks with the thresholds exchanged inside the joins: the
     merged null maxima and top-k are the oracle's."""
+    entered("sharded_plan", BASE + 100000 + case)
     cfg, env = draw(BASE + 100000 + case)
     env["GCRE_WINDOW_TILES"] = ""
     env["GCRE_EXCHANGE_UNIT"] = str([5, 50, 2000][case % 3])
@@ -134,6 +150,7 @@ def test_random_sharded_plan_matches_oracle(case, monkeypatch):
 def test_random_resident_plan_with_kept_inspections(case, monkeypatch):
     """ResidentPlan over the same draw: a pass, a pass that keeps its inspections, a pass that replays them under another
     permutation window -- each the oracle's."""
+    entered("kept_inspections", BASE + 200000 + case)
     cfg, env = draw(BASE + 200000 + case)
     env["GCRE_WINDOW_TILES"] = ""
     for k, v in env.items():
@@ -162,6 +179,7 @@ def test_random_resident_plan_with_kept_inspections(case, monkeypatch):
 def test_random_problem_on_several_device_threads(case, monkeypatch):
     """gcre_process_paths_devices with device 0 listed 2..4 times (one context and host thread each, shards, the host-side
     threshold hub inside the joins): the oracle's results."""
+    entered("several_device_threads", BASE + 300000 + case)
     cfg, env = draw(BASE + 300000 + case)
     env["GCRE_EXCHANGE_UNIT"] = str([5, 50, 2000][case % 3])
     for k, v in env.items():

@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ab
 for v in ${VARIANTS:--}; do
   if [ "$v" = "-" ]; then unset GCRE_LIB; else export GCRE_LIB=geneticscre_amd/variants/libgcre_hip_$v.so; fi
-  python3 bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity ${BENCH_ARGS} > gpurun_out/ab/$v.json 2> gpurun_out/ab/$v.err || { echo "$v FAILED"; tail -3 gpurun_out/ab/$v.err; continue; }
+  python3 bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs ${BENCH_ARGS} > gpurun_out/ab/$v.json 2> gpurun_out/ab/$v.err || { echo "$v FAILED"; tail -3 gpurun_out/ab/$v.err; continue; }
   python3 - "$v" <<'PY'
 import json, sys
 v = sys.argv[1]

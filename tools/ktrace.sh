@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/kt && mkdir -p gpurun_out/kt
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -- python3 bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity ${BENCH_ARGS} > gpurun_out/kt/bench.json 2> gpurun_out/kt/err.log || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -- python3 bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs ${BENCH_ARGS} > gpurun_out/kt/bench.json 2> gpurun_out/kt/err.log || exit 1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/kt/**/*kernel_stats.csv", recursive=True)[0]

@@ -5,16 +5,16 @@ cd $GRAFT_REPO_ROOT
 TAG=${TAG:-r02_a}
 HEAD_SHA=${HEAD_SHA:-unknown}
 rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity > gpurun_out/prof/bench_kt.json 2> gpurun_out/prof/kt.err || exit 1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity > /dev/null 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/prof/tcc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity > /dev/null 2>&1 || exit 1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d gpurun_out/prof/sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity > /dev/null 2>&1 || exit 1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/prof/sq2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs > gpurun_out/prof/bench_kt.json 2> gpurun_out/prof/kt.err || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs > /dev/null 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/prof/tcc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs > /dev/null 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d gpurun_out/prof/sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs > /dev/null 2>&1 || exit 1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/prof/sq2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs > /dev/null 2>&1 || exit 1
 python3 - "$TAG" "$HEAD_SHA" <<'PY'
 import csv, glob, collections, json, sys, shutil
 tag, head = sys.argv[1], sys.argv[2]
 out = {"_provenance": "rocprofv3 --pmc passes (separate: FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum | SQ issue/wait | SQ instruction mix), --kernel-trace only, "
-       "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity; raw counter sums over the dispatches of each kernel; FETCH/WRITE_SIZE in KB "
+       "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs; raw counter sums over the dispatches of each kernel; FETCH/WRITE_SIZE in KB "
        "(MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of 16-B/lane streams: traffic_bytes_per_null_launch "
        "doubles it -- exact for the plane loads, an upper bound for the 4-B/lane mask-row loads)",
        "workload": "roofline", "head": head, "kernels": {}}

@@ -4,10 +4,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/sens
 for r in 0.01 0.025 0.05; do
-  python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --carrier-rate $r > gpurun_out/sens/rate_$r.json 2> gpurun_out/sens/rate_$r.err || exit 1
+  python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs --carrier-rate $r > gpurun_out/sens/rate_$r.json 2> gpurun_out/sens/rate_$r.err || exit 1
 done
-GCRE_IE_PRUNE=0 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity > gpurun_out/sens/noprune.json 2> gpurun_out/sens/noprune.err || exit 1
-python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity > gpurun_out/sens/default.json 2> gpurun_out/sens/default.err || exit 1
+GCRE_IE_PRUNE=0 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs > gpurun_out/sens/noprune.json 2> gpurun_out/sens/noprune.err || exit 1
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs > gpurun_out/sens/default.json 2> gpurun_out/sens/default.err || exit 1
 python3 - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/sens/*.json")):

@@ -3,9 +3,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/sweep
 for c in subgraph sharded signed; do
-  python3 bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity > gpurun_out/sweep/$c.json 2> gpurun_out/sweep/$c.err || exit 1
+  python3 bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs > gpurun_out/sweep/$c.json 2> gpurun_out/sweep/$c.err || exit 1
 done
-python3 bench.py --method method2 --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity > gpurun_out/sweep/roofline_method2.json 2> gpurun_out/sweep/m2.err || exit 1
+python3 bench.py --method method2 --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-steady-state --no-sensitivity --no-other-configs > gpurun_out/sweep/roofline_method2.json 2> gpurun_out/sweep/m2.err || exit 1
 python3 - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/sweep/*.json")):
