@@ -109,6 +109,37 @@ def host_threads() -> int:
     return n
 
 
+def host_cpu():
+    """CPU model of this host and whether it has AVX-512 VPOPCNTDQ (what the reference's popcount loop vectorises to under
+    -O3 -march=native, reference INSTALL:8 / src/methods.h:81-82)."""
+    model, flags = "unknown", set()
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("flags") and not flags:
+                flags = set(ln.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return {"model": model, "avx512_vpopcntdq": "avx512_vpopcntdq" in flags, "avx512f": "avx512f" in flags, "avx2": "avx2" in flags}
+
+
+def binary_has(path, mnemonic) -> bool:
+    """Does the compiled reference code contain this instruction (objdump of the binary that is timed)?"""
+    import shutil
+    import subprocess
+    for tool in ("objdump", "/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        exe = shutil.which(tool) or (tool if os.path.exists(tool) else None)
+        if not exe:
+            continue
+        try:
+            out = subprocess.run([exe, "-d", path], capture_output=True, text=True, timeout=60).stdout
+            return mnemonic in out
+        except (OSError, subprocess.SubprocessError):
+            continue
+    return False
+
+
 def cpu_baseline(prob, masks, budget_s=15.0):
     """The CPU oracle (oracle/, a port of the reference's JoinExec) timed on a bounded sample of the same
     workload: a prefix of the deepest level's join index, all K permutations, all host cores."""
@@ -153,7 +184,7 @@ def cpu_baseline(prob, masks, budget_s=15.0):
     want_paths = rate * budget_s / max(prob.iterations, 1)
     n_uids = int(min(len(u), max(n_try, np.searchsorted(u.path_idx[1:], want_paths) + 1)))
     t, paths, port_res = run(n_uids)
-    port = {"value": paths * prob.iterations / t, "unit": "scores/s", "cores": threads, "kind": "port",
+    port = {"value": paths * prob.iterations / t, "unit": "scores/s", "cores": threads, "kind": "port", "cpu": host_cpu(),
             "sample": f"level-{name} join, first {n_uids} uids = {paths} joined paths x {prob.iterations} permutations, "
                       f"{t:.1f} s wall, oracle/gcre_oracle.cpp -O3 -march=native"}
     ref = reference_baseline(prob, masks, u, n_uids, p0, p1, threads, port_res)
@@ -215,6 +246,10 @@ def reference_baseline(prob, masks, u, n_uids, p0, p1, threads, port_res):
                      f"{res['seconds']:.1f} s wall; reference src/methods.h score_permute via {os.path.basename(binary)} "
                      f"(partial reference build, -O3 AVX-512/AVX2; driver-side thread pool)",
            "null_maxima_equal_port": same}
+    out["cpu"] = host_cpu()
+    out["binary"] = {"name": os.path.basename(binary),
+                     "flags": "-O3 -march=x86-64-v4 -mavx512vpopcntdq" if binary.endswith("_v4") else "-O3 -mavx2 -mpopcnt",
+                     "vpopcntq_emitted": binary_has(binary, "vpopcntq")}
     # the same sample through the HIP library: reference code <-> GPU at this mask width and permutation count, every run
     try:
         from geneticscre_amd import api

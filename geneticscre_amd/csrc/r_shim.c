@@ -142,6 +142,33 @@ static SEXP score_list(const gcre_result* r) {
   return out;
 }
 
+/* The five native results turned into the R list, and the ONE place that frees them.  Every R allocation below can leave
+ * through a longjmp (allocation failure, interrupt): R_ExecWithCleanup runs release_results on that road too, so no
+ * gcre_result outlives the call whatever happens while the list is built. */
+static SEXP build_result_list(void* p) {
+  gcre_result* res = (gcre_result*)p;
+  /* list(lst1 = ..., ..., lst5 = ...); levels above path_length stay NULL (wrapper.cpp:223) */
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 5));
+  SEXP nms = PROTECT(Rf_allocVector(STRSXP, 5));
+  static const char* names[5] = {"lst1", "lst2", "lst3", "lst4", "lst5"};
+  for (int i = 0; i < 5; i++) {
+    SET_STRING_ELT(nms, i, Rf_mkChar(names[i]));
+    if (res[i].n >= 0) SET_VECTOR_ELT(out, i, score_list(&res[i]));
+  }
+  Rf_setAttrib(out, R_NamesSymbol, nms);
+  UNPROTECT(2);
+  return out;
+}
+
+static void release_results(void* p) {
+  gcre_result* res = (gcre_result*)p;
+  for (int i = 0; i < 5; i++)
+    if (res[i].n >= 0) {
+      G.result_free(&res[i]);
+      res[i].n = -1;
+    }
+}
+
 /* ProcessPaths -- same 39 arguments, same order as src/wrapper.cpp:177-185 / R/RcppExports.R:12-14 */
 SEXP _geneticsCRE_ProcessPaths(
     SEXP src1, SEXP trg1, SEXP cl1, SEXP sg1, SEXP src1b, SEXP trg1b, SEXP cl1b, SEXP sg1b,
@@ -219,19 +246,9 @@ SEXP _geneticsCRE_ProcessPaths(
   const int rc = G.process_paths_devices(m, nc, nt, K, Rf_asInteger(top_k), ndev ? devs : NULL, ndev, &in, res, msg, sizeof msg);
   if (rc != GCRE_OK) Rf_error("geneticsCRE: %s", msg[0] ? msg : "gcre_process_paths_devices failed");
 
-  /* list(lst1 = ..., ..., lst5 = ...); levels above path_length stay NULL (wrapper.cpp:223) */
-  SEXP out = PROTECT(Rf_allocVector(VECSXP, 5));
-  SEXP nms = PROTECT(Rf_allocVector(STRSXP, 5));
-  static const char* names[5] = {"lst1", "lst2", "lst3", "lst4", "lst5"};
-  for (int i = 0; i < 5; i++) {
-    SET_STRING_ELT(nms, i, Rf_mkChar(names[i]));
-    if (res[i].n >= 0) {
-      SET_VECTOR_ELT(out, i, score_list(&res[i]));
-      G.result_free(&res[i]);
-    }
-  }
-  Rf_setAttrib(out, R_NamesSymbol, nms);
-  UNPROTECT(2 + np);
+  /* all five lists are built before any result is freed, and the results are freed in one place -- on the error road too */
+  SEXP out = R_ExecWithCleanup(build_result_list, res, release_results, res);
+  UNPROTECT(np);
   return out;
 }
 

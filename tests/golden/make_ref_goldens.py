@@ -26,9 +26,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+from geneticscre_amd import api  # noqa: E402
 from geneticscre_amd.harness_io import problem_digest, write_problem, write_problem_bin  # noqa: E402
 from geneticscre_amd.synth import make_problem  # noqa: E402
-from helpers import WIDE_CASES, small_table, wide_problem  # noqa: E402
+from helpers import SLOW_WIDE_CASES, WIDE_CASES, small_table, wide_problem  # noqa: E402
 
 DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
 OUT = os.path.join(HERE, "ref_cases")
@@ -45,7 +46,8 @@ CASES = [
 ]
 
 
-def main(out=OUT, wide=True):
+def main(out=OUT, wide=True, slow=True):
+    """slow=False leaves out the cases of SLOW_WIDE_CASES (minutes of reference time each); INDEX.json names them all."""
     os.makedirs(out, exist_ok=True)
     index = []
     for name, method, genes, edges, nc, nt, rows, iters, length, top_k, seed, table in CASES:
@@ -68,6 +70,9 @@ def main(out=OUT, wide=True):
     if wide:
         import tempfile
         for name, (method, genes, edges, nc, nt, perms, length, top_k, seed) in WIDE_CASES.items():
+            wide_index.append(name)
+            if name in SLOW_WIDE_CASES and not slow:
+                continue
             p = wide_problem(name)
             with tempfile.TemporaryDirectory() as tmp:
                 blob = os.path.join(tmp, name + ".gcrebin")
@@ -75,13 +80,13 @@ def main(out=OUT, wide=True):
                 res = json.loads(subprocess.run([DRIVER, "--bin", blob], check=True, capture_output=True, text=True).stdout)
             res["_case"] = {"method": method, "iterations": perms, "top_k": top_k, "path_length": length,
                             "generator": {"genes": genes, "edges": edges, "cases": nc, "ctrls": nt, "seed": seed,
-                                          "table": "gcre_values_table"},
+                                          "table": "gcre_values_table",
+                                          "table_exact_order": bool(api.values_table_exact_order(nc, nt))},
                             "mask_words": (nc + nt + 63) // 64,
                             "paths": {k: int(v) for k, v in p.levels.n_paths.items()},
                             "input_sha256": problem_digest(p)}
             with open(os.path.join(out, name + ".json"), "w") as f:
                 json.dump(res, f, separators=(",", ":"))
-            wide_index.append(name)
             print(name, (nc + nt + 63) // 64, "words", {k: v for k, v in p.levels.n_paths.items()})
     with open(os.path.join(out, "INDEX.json"), "w") as f:
         json.dump({"_provenance": __doc__.strip().splitlines()[0], "cases": index, "wide_cases": wide_index}, f, indent=1)

@@ -64,7 +64,16 @@ WIDE_CASES = {
     "w79_m2": ("method2", 200, 700, 2400, 2600, 300, 4, 20, 214),
     "w157_m1": ("method1", 200, 700, 4300, 5700, 300, 4, 20, 215),
     "w157_m2": ("method2", 200, 700, 4300, 5700, 300, 4, 20, 216),
+    # round 4: path length 5 (paths3 x paths3, src/wrapper.cpp:271-276) at the width of configs[2], both methods, and the
+    # signed method at 313 words (20,000 patients: the sorted-prefix-sum form of the native table builder)
+    "w79_m1_len5": ("method1", 110, 300, 2450, 2550, 300, 5, 20, 217),
+    "w79_m2_len5": ("method2", 110, 300, 2450, 2550, 300, 5, 20, 218),
+    "w313_m2": ("method2", 70, 200, 9400, 10600, 150, 4, 20, 219),
 }
+# goldens whose reference run takes minutes (the reference's signed method copies and symmetrises its padded (n+1)^2 table
+# once per join, src/methods.h:128: 230 s at 20,000 patients): committed like the others, checked against the oracle and
+# the GPU like the others, but cut again by test_committed_goldens_regenerate only under GCRE_SLOW_GOLDENS=1
+SLOW_WIDE_CASES = {"w313_m2"}
 _WIDE_TABLES: dict = {}
 _WIDE_PROBLEMS: dict = {}
 

@@ -41,3 +41,4 @@ int Rf_nrows(SEXP);
 int Rf_ncols(SEXP);
 void Rf_error(const char*, ...) __attribute__((noreturn));
 char* R_alloc(size_t, int);
+SEXP R_ExecWithCleanup(SEXP (*fun)(void*), void* data, void (*cleanfun)(void*), void* cleandata);
