@@ -95,6 +95,7 @@ EXPORTS = [
     "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask", "gcre_uids_set_reduced",
     "gcre_set_perm_window", "gcre_plan_perm_window", "gcre_process_paths_devices",
     "gcre_set_inspect_cache", "gcre_drop_inspections", "gcre_build_flags", "gcre_device_count",
+    "gcre_rccl_selftest", "gcre_rccl_collectives",
 ]
 
 
@@ -173,6 +174,8 @@ def load_library():
     lib.gcre_levels_free.restype = None
     lib.gcre_values_table.argtypes = [I, I, P]
     lib.gcre_values_table_exact_order.argtypes = [I, I]
+    lib.gcre_rccl_selftest.argtypes = [I, ctypes.c_char_p, ctypes.c_size_t]
+    lib.gcre_rccl_collectives.restype = ctypes.c_int64
     lib.gcre_generate_perm_masks.argtypes = [V, ctypes.c_uint64, P, I]
     lib.gcre_mix64.restype = ctypes.c_uint64
     lib.gcre_mix64.argtypes = [ctypes.c_uint64]
@@ -526,6 +529,17 @@ def values_table(n_cases: int, n_ctrls: int) -> np.ndarray:
     if rc != GCRE_OK:
         raise ValueError("bad table dimensions")
     return out
+
+
+def rccl_selftest(device: int = 0) -> None:
+    """One-rank RCCL communicator + MAX all-reduce through the library's own (dlopen'ed) RCCL binding; raises on failure."""
+    buf = ctypes.create_string_buffer(512)
+    if load_library().gcre_rccl_selftest(int(device), buf, 512) != GCRE_OK:
+        raise GcreError("gcre_rccl_selftest: " + buf.value.decode())
+
+
+def rccl_collectives() -> int:
+    return int(load_library().gcre_rccl_collectives())
 
 
 def values_table_exact_order(n_cases: int, n_ctrls: int) -> bool:

@@ -7,8 +7,12 @@
 #include "../../include/gcre_hip.h"
 #include "gcre_kernels.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen'ed where several devices are used (RcclApi)
+
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -150,8 +154,44 @@ struct HostTimer {
 
 }  // namespace
 
+// RCCL, loaded on first use (gcre_process_paths_devices with several distinct devices, gcre_rccl_selftest): the library
+// does not link librccl, so a one-GPU user -- the R drop-in's default -- never needs it.  north_star: "RCCL all-reduce over
+// xGMI of the per-permutation null maxima": ncclAllReduce(ncclMax) on each device's stream, in place on the device, for
+// the thresholds shared inside a join and for the per-level merge; the host hub below stays the fallback (RCCL missing,
+// a device listed twice) and the place where the device threads meet under a deadline before every collective.
+std::atomic<int64_t> g_rccl_collectives{0};   // RCCL collectives issued by this process (gcre_rccl_collectives)
+
+struct RcclApi {
+  void* so = nullptr;
+  decltype(&ncclCommInitAll) comm_init_all = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+  bool ok = false;
+  static RcclApi& get() {
+    static RcclApi api = [] {
+      RcclApi a;
+      const char* off = std::getenv("GCRE_RCCL");
+      if (off && std::strcmp(off, "0") == 0) return a;   // GCRE_RCCL=0: host hub only
+      for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        a.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (a.so) break;
+      }
+      if (!a.so) return a;
+      a.comm_init_all = (decltype(a.comm_init_all))dlsym(a.so, "ncclCommInitAll");
+      a.comm_destroy = (decltype(a.comm_destroy))dlsym(a.so, "ncclCommDestroy");
+      a.all_reduce = (decltype(a.all_reduce))dlsym(a.so, "ncclAllReduce");
+      a.error_string = (decltype(a.error_string))dlsym(a.so, "ncclGetErrorString");
+      a.ok = a.comm_init_all && a.comm_destroy && a.all_reduce && a.error_string;
+      return a;
+    }();
+    return api;
+  }
+};
+
 // gcre_process_paths_devices: the device threads of one call meet here to MAX-merge their running null maxima during a
-// join (gcre_join_opts.exchange, served inside the library).  K floats per call: the host does the reduction.
+// join (gcre_join_opts.exchange, served inside the library).  K floats per call: the host does the reduction.  With RCCL
+// the data stays on the devices and only the meeting (`meet`) happens here.
 struct ExchangeHub {
   int n = 0;
   std::mutex m;
@@ -194,6 +234,11 @@ struct ExchangeHub {
     }
     mine = result;
     return 0;
+  }
+  // every device arrives with the same tag or the round fails; no data (the collective that follows moves it)
+  int meet(uint64_t tag) {
+    std::vector<float> none;
+    return reduce(none, tag);
   }
   void fail() {
     std::lock_guard<std::mutex> lk(m);
@@ -247,6 +292,8 @@ struct gcre_ctx {
   uint64_t obs_epoch = 0;            // bumped whenever the value table changes: observed scores (keys, winners) are per epoch
   bool insp_cache = false;           // gcre_set_inspect_cache: a join's inspector output stays with its join index
   ExchangeHub* hub = nullptr;        // set by gcre_process_paths_devices for the duration of a call
+  ncclComm_t comm = nullptr;         // ... and this device's RCCL communicator when the devices are distinct and RCCL loads
+  int64_t rccl_calls = 0;            // collectives this context issued during the call (diagnostics, tests)
   DevBuf<float> d_hub_null;          // the maxima this device hands to the hub
   int hub_level = 0, hub_round = 0;  // what the next exchange of this device is: part of the hub's round tag
   // permutation window [win_k0, win_k0 + win_K): what a join scores.  The whole range by default; gcre_set_perm_window
@@ -2841,8 +2888,18 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
             gcre_ctx* cc = (gcre_ctx*)user;
             std::vector<float> v((size_t)std::max(k1 - k0, 0));
             if (v.empty()) return 0;
-            if (hipMemcpy(v.data(), d_null, v.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { cc->hub->fail(); return 1; }
             const uint64_t tag = ((uint64_t)(uint32_t)cc->hub_level << 48) ^ ((uint64_t)(uint32_t)k0 << 16) ^ (uint64_t)(cc->hub_round++ & 0xffff);
+            if (cc->comm) {
+              // RCCL: the maxima never leave the devices.  The threads meet first (same level, window and exchange on
+              // every device, under the hub's deadline), then each issues the in-place MAX all-reduce on its stream
+              if (cc->hub->meet(tag) != 0) return 1;
+              const ncclResult_t nr = RcclApi::get().all_reduce(d_null, d_null, v.size(), ncclFloat32, ncclMax, cc->comm, cc->stream);
+              cc->rccl_calls++;
+              g_rccl_collectives++;
+              if (nr != ncclSuccess || hipStreamSynchronize(cc->stream) != hipSuccess) { cc->hub->fail(); return 1; }
+              return 0;
+            }
+            if (hipMemcpy(v.data(), d_null, v.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { cc->hub->fail(); return 1; }
             if (cc->hub->reduce(v, tag) != 0) return 1;
             return hipMemcpy(d_null, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
           };
@@ -2852,6 +2909,24 @@ int gcre_process_paths(gcre_ctx* c, const gcre_pp_input* in, gcre_result out[5])
     gcre_result tmp;
     int r = run_join(c, jp, &tmp);
     if (r != GCRE_OK) { gcre_result_free(&tmp); return r; }
+    if (o && c->comm && c->hub && c->win_K > 0 && tmp.null_max) {   // (the 1a join's result is discarded: nothing to merge)
+      // merge_scores across devices (src/methods.h:34-37) over RCCL: element-wise MAX all-reduce of this window's f32 null
+      // maxima, in place on the device -- exact for any sharding (f32 max is associative, the values are f32-rounded).
+      // Every device then returns the merged maxima; the caller's host-side MAX over devices changes nothing any more.
+      const uint64_t tag = ((uint64_t)(uint32_t)lvi << 48) ^ ((uint64_t)(uint32_t)c->win_k0 << 16) ^ 0xffffull;
+      if (c->hub->meet(tag) != 0) { gcre_result_free(&tmp); return fail(c, GCRE_ERR_DEVICE, "the devices did not meet for the level's RCCL merge"); }
+      float* d = (float*)(c->d_null + c->win_k0);
+      const ncclResult_t nr = RcclApi::get().all_reduce(d, d, (size_t)c->win_K, ncclFloat32, ncclMax, c->comm, c->stream);
+      c->rccl_calls++;
+      g_rccl_collectives++;
+      hipError_t he = nr == ncclSuccess ? hipMemcpyAsync(tmp.null_max, d, (size_t)c->win_K * 4, hipMemcpyDeviceToHost, c->stream) : hipErrorUnknown;
+      if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+      if (he != hipSuccess) {
+        c->hub->fail();
+        gcre_result_free(&tmp);
+        return fail(c, GCRE_ERR_DEVICE, std::string("RCCL all-reduce of the null maxima failed: ") + (nr != ncclSuccess ? RcclApi::get().error_string(nr) : hipGetErrorString(he)));
+      }
+    }
     add_prof();
     if (o) *o = tmp; else gcre_result_free(&tmp);
     return GCRE_OK;
@@ -3088,15 +3163,35 @@ int gcre_process_paths_devices(int method, int n_cases, int n_ctrls, int iterati
   ExchangeHub hub;   // where the device threads MAX-merge their running maxima during the large joins
   hub.n = N;
   if (const char* e = std::getenv("GCRE_HUB_TIMEOUT_S")) hub.timeout_s = std::max(0.01, std::atof(e));
+  // RCCL communicators, one per device, when every device is listed once (RCCL refuses a device twice: the one-GPU
+  // rehearsal stays on the host hub) and the library loads.  GCRE_RCCL=0: never; GCRE_RCCL=force: also for one device
+  // (one-rank collectives: what a one-GPU box can exercise of this path).
+  std::vector<ncclComm_t> comms;
+  {
+    const char* mode = std::getenv("GCRE_RCCL");
+    const bool force = mode && std::strcmp(mode, "force") == 0;
+    bool distinct = true;
+    for (int a = 0; a < N; a++)
+      for (int b = a + 1; b < N; b++) distinct = distinct && dev[(size_t)a] != dev[(size_t)b];
+    if (rc == GCRE_OK && distinct && (N > 1 || force) && iterations > 0 && RcclApi::get().ok) {
+      comms.assign((size_t)N, nullptr);
+      if (RcclApi::get().comm_init_all(comms.data(), N, dev.data()) != ncclSuccess) {
+        comms.clear();   // (no communicator: the host hub serves the call)
+        (void)hipGetLastError();
+      }
+    }
+  }
   if (rc == GCRE_OK) {
     auto work = [&](int r) {
       gcre_pp_input mine = *in;
       mine.shard_rank = N > 1 ? r : 0;
       mine.shard_world = N > 1 ? N : 0;
       mine.window_perms = N > 1 ? window : in->window_perms;
-      ctx[(size_t)r]->hub = N > 1 ? &hub : nullptr;
+      ctx[(size_t)r]->hub = (N > 1 || !comms.empty()) ? &hub : nullptr;
+      ctx[(size_t)r]->comm = comms.empty() ? nullptr : comms[(size_t)r];
       rcs[(size_t)r] = gcre_process_paths(ctx[(size_t)r], &mine, part[(size_t)r].data());
       ctx[(size_t)r]->hub = nullptr;
+      ctx[(size_t)r]->comm = nullptr;
       if (rcs[(size_t)r] != GCRE_OK) hub.fail();   // nobody waits for a device that has given up
     };
     std::vector<std::thread> th;
@@ -3156,6 +3251,8 @@ int gcre_process_paths_devices(int method, int n_cases, int n_ctrls, int iterati
       }
     }
   }
+  for (ncclComm_t cm : comms)
+    if (cm) (void)RcclApi::get().comm_destroy(cm);
   for (int r = 0; r < N; r++) {
     if (rcs[(size_t)r] == GCRE_OK)
       for (int lv = 0; lv < 5; lv++)
@@ -3165,6 +3262,40 @@ int gcre_process_paths_devices(int method, int n_cases, int n_ctrls, int iterati
       gcre_destroy(ctx[(size_t)r]);
     }
   }
+  return rc;
+}
+
+int64_t gcre_rccl_collectives(void) { return g_rccl_collectives.load(); }
+
+int gcre_rccl_selftest(int device, char* err, size_t errlen) {
+  auto say = [&](const std::string& m) {
+    if (err && errlen) std::snprintf(err, errlen, "%s", m.c_str());
+  };
+  RcclApi& api = RcclApi::get();
+  if (!api.ok) { say("librccl.so not found (or GCRE_RCCL=0)"); return GCRE_ERR_DEVICE; }
+  if (hipSetDevice(device) != hipSuccess) { say("no such device"); return GCRE_ERR_DEVICE; }
+  ncclComm_t comm = nullptr;
+  ncclResult_t nr = api.comm_init_all(&comm, 1, &device);
+  if (nr != ncclSuccess) { say(std::string("ncclCommInitAll: ") + api.error_string(nr)); return GCRE_ERR_DEVICE; }
+  const size_t n = 4096;
+  std::vector<float> h(n), back(n);
+  for (size_t i = 0; i < n; i++) h[i] = (float)((i * 2654435761u) % 1000u) / 8.0f;
+  float* d = nullptr;
+  hipStream_t st = nullptr;
+  int rc = GCRE_OK;
+  if (hipMalloc((void**)&d, n * 4) != hipSuccess || hipStreamCreate(&st) != hipSuccess) rc = GCRE_ERR_DEVICE;
+  if (rc == GCRE_OK && hipMemcpyAsync(d, h.data(), n * 4, hipMemcpyHostToDevice, st) != hipSuccess) rc = GCRE_ERR_DEVICE;
+  if (rc == GCRE_OK) {
+    nr = api.all_reduce(d, d, n, ncclFloat32, ncclMax, comm, st);   // one rank: MAX over {x} = x
+    g_rccl_collectives++;
+    if (nr != ncclSuccess) { say(std::string("ncclAllReduce: ") + api.error_string(nr)); rc = GCRE_ERR_DEVICE; }
+  }
+  if (rc == GCRE_OK && (hipMemcpyAsync(back.data(), d, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+    rc = GCRE_ERR_DEVICE;
+  if (rc == GCRE_OK && std::memcmp(h.data(), back.data(), n * 4) != 0) { say("one-rank MAX all-reduce changed the data"); rc = GCRE_ERR_DEVICE; }
+  if (d) (void)hipFree(d);
+  if (st) (void)hipStreamDestroy(st);
+  (void)api.comm_destroy(comm);
   return rc;
 }
 

@@ -221,6 +221,16 @@ int gcre_process_paths(gcre_ctx* ctx, const gcre_pp_input* in, gcre_result out[5
 int gcre_process_paths_devices(int method, int n_cases, int n_ctrls, int iterations, int top_k, const int* devices,
                                int n_devices, const gcre_pp_input* in, gcre_result out[5], char* err, size_t errlen);
 
+/* RCCL inside gcre_process_paths_devices.  When every device is listed once and librccl.so loads (dlopen: the library does
+ * not link it), each device gets a communicator (ncclCommInitAll) and the K-float null maxima are merged by
+ * ncclAllReduce(ncclFloat32, ncclMax) in place on the devices -- once per level and permutation window (merge_scores,
+ * src/methods.h:34-37) and at every threshold exchange inside a large join; the top-k tables (top_k rows per device) are
+ * merged on the host.  Environment: GCRE_RCCL=0 host-side merge only, GCRE_RCCL=force communicators for a single device
+ * too (one-rank collectives).  gcre_rccl_selftest: a one-rank communicator on `device`, one MAX all-reduce, checked;
+ * gcre_rccl_collectives: RCCL collectives this process has issued so far. */
+int gcre_rccl_selftest(int device, char* err, size_t errlen);
+int64_t gcre_rccl_collectives(void);
+
 /* uid resolution of assemble_uids (src/wrapper.cpp:106-132): row k takes (count, location) of the entry
  * keyed by trg_uids[k]; missing keys give (0, 0). */
 int gcre_resolve_count_locs(const int32_t* trg_uids, int64_t n_uids,

@@ -378,6 +378,30 @@ def test_process_paths_on_several_devices_from_one_process(method, devices, wind
         assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
 
 
+def test_rccl_selftest_through_the_librarys_own_binding():
+    """libgcre_hip.so dlopens librccl.so itself (no torch in between): a one-rank communicator on device 0 and one
+    ncclAllReduce(ncclFloat32, ncclMax), checked -- what a one-GPU box can run of the multi-GPU merge."""
+    before = api.rccl_collectives()
+    api.rccl_selftest(0)
+    assert api.rccl_collectives() == before + 1
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+def test_process_paths_devices_merges_the_maxima_over_rccl(method, monkeypatch):
+    """GCRE_RCCL=force: gcre_process_paths_devices creates a communicator even for ONE device and merges every level's null
+    maxima with ncclAllReduce(MAX) on the device (two permutation windows: one collective per level and window).  With
+    several distinct devices the same code runs with N ranks; on this box it is the one-rank case.  Results: the oracle's."""
+    monkeypatch.setenv("GCRE_RCCL", "force")
+    monkeypatch.setenv("GCRE_WINDOW_TILES", "1")
+    p = make_problem(60, 200, 33, 41, 2300, 4, method=method, top_k=11, seed=23, table=small_table(33, 41, 6))
+    want = oracle.process_paths(p, order="canonical", nthreads=4)
+    before = api.rccl_collectives()
+    got = api.process_paths_devices(p, [0])
+    assert api.rccl_collectives() - before == 4 * 2      # lst1..lst4 (the 1a join's result is discarded, its merge is not needed) x 2 windows
+    for lvl in range(1, 5):
+        assert_same_result(got[f"lst{lvl}"], want[f"lst{lvl}"])
+
+
 def test_native_harness_reproduces_the_reference_harness_output():
     """tools/harness/gcre_harness (the counterpart of the reference's test/harness.cpp) on SURVEY.md Appendix B's dump
     with the flags of the four recorded runs of the unmodified reference binary: the printed level-4 scores and null
