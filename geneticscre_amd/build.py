@@ -14,7 +14,7 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-
 # Defines that switch parts of a kernel off for timing experiments ("results are wrong") must never reach the shipped
 # library: build() refuses them unless GCRE_ALLOW_DIAG_BUILD=1, and the library reports what it was built with
 # (gcre_build_flags) so that smoke() and the tests can assert a clean build.
-DIAG_DEFINES = ("GCRE_IEQ_NOPATHS", "GCRE_IEQ_NOEXACT", "GCRE_M2_NOLOOKUP", "GCRE_STATS_ZHACK")
+DIAG_DEFINES = ("GCRE_IEQ_NOPATHS", "GCRE_IEQ_NOEXACT", "GCRE_M2_NOLOOKUP", "GCRE_M2_NOROWS", "GCRE_M2_NOZLOAD", "GCRE_STATS_ZHACK")
 
 
 def extra_flags() -> list:

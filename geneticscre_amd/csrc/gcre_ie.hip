@@ -1756,6 +1756,241 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? G
   if (my_max_len > 8u) atomicMax(a.max_tot + 5, my_max_len);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The signed method's inspector, block-staged like k_stats_ie2 (round 4).  A joined path is two half-rows; every 16-lane
+// group works on ONE (path, half) -- a "virtual row" -- so a wave owns 32 consecutive joined paths = 64 virtual rows, the
+// group's half is fixed (group & 1: a group that stays on the same paths0 row keeps that half's words), and the per-half
+// outputs (carriers, carriers among the cases, list info, list slot) are staged in LDS exactly as the unsigned kernel
+// stages its per-path ones.  What needs both halves -- the observed score vt[case_pos][ctrl_neg] + vt[case_neg][ctrl_pos]
+// (methods.h:255), the reported counts (:256-257) -- is put together per path when the block is written out.
+// Same outputs as k_stats_ie<2, .>, bit for bit (GCRE_STATS_V1=1 runs that one).
+// ------------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? GCRE_STATS_WAVES : 2))) void k_stats_ie2s(const StatsArgs a) {
+  typedef u64 __attribute__((ext_vector_type(2))) u64x2;
+  constexpr u32 kNoRange = 0xffffffffu;
+  constexpr u32 kOverChunk = 2048;
+  __shared__ u32 slot_lds[4][64 * 8];   // the 64 virtual rows' list slots
+  __shared__ u32 out_lds[4][4][64];     // per virtual row: carriers, carriers among the cases, linfo, lover
+  __shared__ u32 pair_lds[4][4][3][32 * NL];
+  __shared__ u32 meta_lds[4][4][32];    // per path: paths0 row, reduced row | flip, range, swap of paths1
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sl = lane & 15, grp = lane >> 4;
+  const int h = grp & 1;                // the half this group works on, in the joined path's orientation
+  const u32 gsh = (u32)grp * 16u, ltm = (1u << sl) - 1u;
+  u32 (*pairs)[32 * NL] = pair_lds[wv][grp];
+  u32 (*meta)[32] = meta_lds[wv];
+  const i64 wave = (i64)blockIdx.x * 4 + wv;
+  const i64 nwaves = (i64)gridDim.x * 4;
+  const int Wp = a.Wp;
+  u32* slots = slot_lds[wv];
+  u32 (*outs)[64] = out_lds[wv];
+  u32 my_max_tot = 0, my_modes = 0, my_max_len = 0;
+  bool my_bad = false;
+  u32 chunk_at = 0u, chunk_left = 0u;
+  __shared__ u64 cm_lds[32 * NL];
+  for (int k = (int)threadIdx.x; k < 32 * NL; k += 256) cm_lds[k] = k < Wp ? a.case_mask[k] : 0;
+  __syncthreads();
+  const i64 nblocks = (a.count + 31) / 32;
+  for (i64 blk = wave; blk < nblocks; blk += nwaves) {
+    const i64 base = blk * 32;
+    {
+      // ---- the 32 paths' row numbers (lanes t and t + 32 both read path base + t) ----
+      const i64 iq = base + (lane & 31) < a.count ? base + (lane & 31) : a.count - 1;
+      const u32 r0v = a.row0[iq];
+      const u32 r1v = a.row1[iq];
+      const u32 zraw = a.zindex ? (u32)a.zindex[r1v & 0x7fffffffu] : (r1v & 0x7fffffffu);
+      const u32 zflip = (r1v ^ (a.zindex ? zraw : 0u)) & 0x80000000u;
+      u32 rngv = kNoRange;   // the uid's row of the excess table, for the first path of a uid in this launch only
+      if (a.excess && (iq == 0 || a.row0[iq - 1] != r0v)) rngv = (u32)a.range_of[r0v];
+      if (lane < 32) {
+        meta[0][lane] = r0v;
+        meta[1][lane] = (zraw & 0x7fffffffu) | zflip;
+        meta[2][lane] = rngv;
+        meta[3][lane] = r1v >> 31;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      const u32x4 pad = {a.zoff, a.zoff, a.zoff, a.zoff};
+      ((u32x4*)slots)[lane * 2] = pad;
+      ((u32x4*)slots)[lane * 2 + 1] = pad;
+    }
+    u64 xw[NL][2], zw[NL][2];
+#pragma unroll
+    for (int it = 0; it < NL; it++) xw[it][0] = xw[it][1] = zw[it][0] = zw[it][1] = 0ull;
+    u32 n_rzf = 0u, n_rng = kNoRange, n_r0 = 0xffffffffu, n_swap = 0u;
+    auto fetch_rows = [&](int itn) {
+      const int pln = (itn * 4 + grp) >> 1;
+      const u32 r0n = meta[0][pln];
+      n_rzf = meta[1][pln];
+      n_rng = meta[2][pln];
+      n_swap = meta[3][pln];
+      const bool new_x = r0n != n_r0;
+      n_r0 = r0n;
+      const int hz = (n_rzf >> 31) ? 1 - h : h;   // the reduced row's half that lands in half h
+      const u64* xn = a.p0 + (size_t)r0n * a.S + (size_t)h * Wp;
+      const u64* zn = a.pz + (size_t)(n_rzf & 0x7fffffffu) * a.S + (size_t)hz * Wp;
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+        const int k = it * 32 + 2 * sl;
+        if (k < Wp) {
+          if (new_x) {
+            const u64x2 v = *(const u64x2*)(xn + k);
+            xw[it][0] = v.x; xw[it][1] = v.y;
+          }
+          const u64x2 v = *(const u64x2*)(zn + k);
+          zw[it][0] = v.x; zw[it][1] = v.y;
+        }
+      }
+    };
+    fetch_rows(0);
+    for (int it8 = 0; it8 < 16; it8++) {
+      const int vl = it8 * 4 + grp;                 // the group's virtual row inside the block
+      const int pl = vl >> 1;                       // ... and its path
+      const bool active = base + pl < a.count;
+      if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+      const u32 rng = n_rng, swap = n_swap;
+      // the excess row is in paths1's orientation: its half (swap ? 1 - h : h) lands in half h
+      const u64* uu = (rng != kNoRange) ? a.excess + (size_t)rng * a.S + (size_t)(swap ? 1 - h : h) * Wp : nullptr;
+      u64* out = (a.res && active) ? a.res + (size_t)(a.first + base + pl) * a.S + (size_t)h * Wp : nullptr;
+      u32 cc = 0u, dv = 0u;
+      u64 stray = 0;
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+        const int k = it * 32 + 2 * sl;
+        u64x2 uv = {0, 0};
+        if (k < Wp && uu) uv = *(const u64x2*)(uu + k);
+        const u64x2 cmv = *(const u64x2*)(cm_lds + k);
+        const u64 cme[2] = {cmv.x, cmv.y};
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const u64 xk = xw[it][e], zk = zw[it][e], uk = e ? uv.y : uv.x;
+          stray |= uk & ~xk;
+          const u64 j = xk | zk;
+          cc += (u32)__popcll(j & cme[e]) | ((u32)__popcll(j) << 16);
+          dv += (u32)__popcll(zk & ~xk) | ((u32)__popcll(zk) << 16);
+        }
+        if (out && k < Wp) *(u64x2*)(out + k) = u64x2{xw[it][0] | zw[it][0], xw[it][1] | zw[it][1]};
+      }
+      if (stray) my_bad = true;
+      const u32 c = row_total(cc, lane), d = row_total(dv, lane);
+      const u32 inc = c & 0xffffu, tot = c >> 16;
+      const u32 dl = d & 0xffffu, ov = (d >> 16) - dl;
+      const u32 mode = a.ie_rule ? ((ov <= 8u || ov < dl) ? 1u : 0u) : ((a.ie_bias >= 0 && ov + (u32)a.ie_bias < dl) ? 1u : 0u);
+      const u32 len = mode ? ov : dl;
+      const u32 len8 = max(8u, (len + 7u) & ~7u);
+      u32 npair = 0u;
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const u64 w = mode ? (zw[it][e] & xw[it][e]) : (zw[it][e] & ~xw[it][e]);
+          const bool nz = active && w != 0;
+          const u64 bal = __builtin_amdgcn_ballot_w64(nz);
+          if (bal == 0ull) continue;
+          const u32 m = (u32)(bal >> gsh) & 0xffffu;
+          const u32 at = npair + (u32)__builtin_popcount(m & ltm);
+          if (nz) {
+            pairs[0][at] = (u32)w;
+            pairs[1][at] = (u32)(w >> 32);
+            pairs[2][at] = (u32)(it * 32 + 2 * sl + e);
+          }
+          npair += (u32)__builtin_popcount(m);
+        }
+      }
+      fetch_rows(it8 < 15 ? it8 + 1 : 15);   // (changes the NEXT iteration's words and row numbers only)
+      if (active && sl == 0) {
+        my_modes += mode;
+        my_max_tot = max(my_max_tot, tot);
+        my_max_len = max(my_max_len, len8);
+      }
+      const u32 need = (active && len8 > 8u) ? len8 - 8u : 0u;
+      const u32 n0 = rdlane(need, 0), n1 = rdlane(need, 16), n2 = rdlane(need, 32), n3 = rdlane(need, 48);
+      const u32 nsum = n0 + n1 + n2 + n3;
+      u32 ovb = 0u;
+      if (nsum != 0u) {
+        if (chunk_left < nsum) {
+          const u32 grab = nsum > kOverChunk ? nsum : kOverChunk;
+          u32 wbase = 0u;
+          if (lane == 0) wbase = atomicAdd(a.ov_count, grab);
+          chunk_at = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
+          chunk_left = grab;
+        }
+        ovb = chunk_at + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        chunk_at += nsum;
+        chunk_left -= nsum;
+      }
+      const bool ov_ok = active && len8 > 8u && (u64)ovb + (len8 - 8u) <= (u64)a.over_cap;
+      u32* over = a.over + ovb;
+      __builtin_amdgcn_wave_barrier();
+      {
+        const u32 npmax = max(max(rdlane(npair, 0), rdlane(npair, 16)), max(rdlane(npair, 32), rdlane(npair, 48)));
+        u32 cnt = 0u;
+        for (u32 q0 = 0u; q0 < npmax; q0 += 16u) {
+          const u32 pi = q0 + (u32)sl;
+          const bool has = pi < npair;
+          u64 w = has ? ((u64)pairs[1][pi] << 32) | (u64)pairs[0][pi] : 0ull;
+          const u32 k = has ? pairs[2][pi] : 0u;
+          while (__builtin_amdgcn_ballot_w64(w != 0ull) != 0ull) {
+            const bool nzb = w != 0ull;
+            const u32 m = (u32)(__builtin_amdgcn_ballot_w64(nzb) >> gsh) & 0xffffu;
+            const u32 pos = cnt + (u32)__builtin_popcount(m & ltm);
+            const u32 b = nzb ? (u32)__builtin_ctzll(w) : 0u;
+            w &= w - 1ull;
+            const u32 en = (k * 64u + b) << 8;
+            if (nzb) {
+              if (pos < 8u) slots[vl * 8 + (int)pos] = en;
+              else if (ov_ok) over[pos - 8u] = en;
+            }
+            cnt += (u32)__builtin_popcount(m);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (u32 p = max(len, 8u) + (u32)sl; p < len8; p += 16)   // padding of the overflow part
+        if (ov_ok) over[p - 8u] = a.zoff;
+      if (active && sl == 0) {
+        outs[0][vl] = tot;
+        outs[1][vl] = inc;
+        outs[2][vl] = len8 | mode | ((len8 - len) << 28);
+        outs[3][vl] = ovb;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- per path: both halves together -> observed score, reported counts (lanes 0..31) ----
+    if (lane < 32 && base + lane < a.count) {
+      const i64 i = base + lane;
+      const u32 tot0 = outs[0][2 * lane], tot1 = outs[0][2 * lane + 1];
+      // (+) half: case_pos = inc0, ctrl_neg = tot0 - inc0; (-) half: ctrl_pos = inc1, case_neg = tot1 - inc1 (methods.h:182-185)
+      const u32 case_pos = outs[1][2 * lane], ctrl_neg = tot0 - case_pos;
+      const u32 ctrl_pos = outs[1][2 * lane + 1], case_neg = tot1 - ctrl_pos;
+      const double score = a.dvt[(size_t)sp_diag_offset(tot0) + case_pos] + a.dvt[(size_t)sp_diag_offset(tot1) + case_neg];
+      a.tot[2 * i] = tot0;
+      a.tot[2 * i + 1] = tot1;
+      a.cases[i] = case_pos + case_neg;        // methods.h:256-257
+      a.ctrls[i] = ctrl_pos + ctrl_neg;
+      a.rowz[i] = meta[1][lane];
+      a.key[i] = ie_score_key(score);
+    }
+    // ---- per virtual row: list info and slot, one coalesced store per array ----
+    if (base * 2 + lane < a.count * 2) {
+      const i64 dd = base * 2 + lane;
+      a.linfo[dd] = outs[2][lane];
+      a.lover[dd] = outs[3][lane];
+      u32x4* dst = (u32x4*)(a.slot + (u64)dd * 8u);
+      dst[0] = ((const u32x4*)slots)[lane * 2];
+      dst[1] = ((const u32x4*)slots)[lane * 2 + 1];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (my_max_tot) atomicMax(a.max_tot, my_max_tot);
+  if (my_bad) *a.bad = 1u;
+  if (my_modes) atomicAdd(a.bad + 1, my_modes);
+  if (my_max_len > 8u) atomicMax(a.max_tot + 5, my_max_len);
+}
+
 hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {
   if (a.count == 0) return hipSuccess;
   static const bool v1 = std::getenv("GCRE_STATS_V1") != nullptr;   // the per-path form (cross-check)
@@ -1769,6 +2004,18 @@ hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {
     else if (nl == 3) hipLaunchKernelGGL((k_stats_ie2<3>), grid, block, 0, stream, a);
     else if (nl == 4) hipLaunchKernelGGL((k_stats_ie2<4>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_stats_ie2<5>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
+  if (method == 2 && !v1 && a.Wp <= 160) {
+    const i64 nb = (a.count + 31) / 32;
+    const i64 blocks = (nb + 3) / 4;
+    const dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), block(256);
+    const int nl = (a.Wp + 31) / 32;
+    if (nl <= 1) hipLaunchKernelGGL((k_stats_ie2s<1>), grid, block, 0, stream, a);
+    else if (nl == 2) hipLaunchKernelGGL((k_stats_ie2s<2>), grid, block, 0, stream, a);
+    else if (nl == 3) hipLaunchKernelGGL((k_stats_ie2s<3>), grid, block, 0, stream, a);
+    else if (nl == 4) hipLaunchKernelGGL((k_stats_ie2s<4>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_stats_ie2s<5>), grid, block, 0, stream, a);
     return hipGetLastError();
   }
   const i64 blocks = (a.count + 15) / 16;   // 4 waves x 4 paths per block and pass

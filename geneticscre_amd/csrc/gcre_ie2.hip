@@ -325,8 +325,13 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
       for (int j = 0; j < 8; j++) yy[j % YW] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j % YW], 0);
     } else if (real > 0u) {
+#ifdef GCRE_M2_NOROWS   // timing experiment (wrong results): no mask-row loads
+#pragma unroll
+      for (int j = 0; j < 4; j++) yy[j] = offs[j];
+#else
 #pragma unroll
       for (int j = 0; j < 4; j++) yy[j] = __builtin_amdgcn_raw_buffer_load_b32(mt, lane4, offs[j], 0);
+#endif
     } else {
 #pragma unroll
       for (int j = 0; j < 4; j++) yy[j] = 0u;
@@ -336,7 +341,11 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
       for (int j = 0; j < GZ; j++) {
         u32x4 v = {0u, 0u, 0u, 0u};
+#ifdef GCRE_M2_NOZLOAD   // timing experiment (wrong results): no plane loads of the added rows
+        v = u32x4{zu, zu + (u32)j, lane4, 0u};
+#else
         if (j < 2 || j < a.gz) v = __builtin_amdgcn_raw_buffer_load_b128(rz, lane4 * 4u + (u32)j * 1024u, 0, 0);   // (a.gz >= 2: plane_groups_for)
+#endif
         ZZ[4 * j + 0] = v.x; ZZ[4 * j + 1] = v.y; ZZ[4 * j + 2] = v.z; ZZ[4 * j + 3] = v.w;
       }
     }
@@ -630,6 +639,9 @@ __global__ __launch_bounds__(64 * kIeWaves) __attribute__((amdgpu_waves_per_eu(L
           m &= valid;
           if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) return;
           n_slow++;
+#ifdef GCRE_M2_NOLOOKUP   // timing experiment (wrong results): the tests run, nothing is looked up
+          return;
+#endif
           enqueue(m, C, B[1], sp_diag_offset(k_tot[t * 2u + hc]), dU, u_empty);
         };
         // one path ahead: the rows and planes of the next path are in flight while this one is computed

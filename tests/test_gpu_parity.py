@@ -175,11 +175,20 @@ def test_hip_matches_reference_scoring_code_at_baseline_widths(name, kernel, mon
         all_bits = [f"{int(b):016x}" for b in every[f"lst{lvl}"].all_scores.view(np.uint64)]
         assert [f"{int(b):016x}" for b in r.scores.view(np.uint64)] == e["scores"], (name, lvl)
         assert [f"{int(b):08x}" for b in r.null.view(np.uint32)] == e["null"], (name, lvl)
-        assert sorted(zip(e["scores"], e["cases"], e["ctrls"])) == \
-               sorted(zip([f"{int(b):016x}" for b in r.scores.view(np.uint64)], r.cases.tolist(), r.ctrls.tolist()))
+        # counts and ids of every score that is not tied among ALL paths of the level are the reference's; a tie -- also one
+        # with a path outside the top-k (w313_m2, level 3: two paths with the same score and different counts at the cut) --
+        # is cut by joined-path ordinal here and by heap arrival order there: those entries are the oracle's
+        # under the canonical rule
+        got_bits = [f"{int(b):016x}" for b in r.scores.view(np.uint64)]
+        untied = [s for s in e["scores"] if all_bits.count(s) == 1]
+        assert sorted((s, c, t) for s, c, t in zip(e["scores"], e["cases"], e["ctrls"]) if s in untied) == \
+               sorted((s, c, t) for s, c, t in zip(got_bits, r.cases.tolist(), r.ctrls.tolist()) if s in untied), (name, lvl)
         for k, s in enumerate(e["scores"]):
             if all_bits.count(s) == 1:
                 assert (r.src[k], r.trg[k]) == (e["src"][k], e["trg"][k]), (name, lvl, k)
+        c = every[f"lst{lvl}"]
+        assert r.src.tolist() == c.src.tolist() and r.trg.tolist() == c.trg.tolist(), (name, lvl)
+        assert r.cases.tolist() == c.cases.tolist() and r.ctrls.tolist() == c.ctrls.tolist(), (name, lvl)
 
 
 @pytest.mark.parametrize("name,p,exp", REF_CASES[:4], ids=[c[0] for c in REF_CASES[:4]])
