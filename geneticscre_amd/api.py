@@ -95,7 +95,7 @@ EXPORTS = [
     "gcre_generate_perm_masks", "gcre_mix64", "gcre_get_perm_mask", "gcre_uids_set_reduced",
     "gcre_set_perm_window", "gcre_plan_perm_window", "gcre_process_paths_devices",
     "gcre_set_inspect_cache", "gcre_drop_inspections", "gcre_build_flags", "gcre_device_count",
-    "gcre_rccl_selftest", "gcre_rccl_collectives",
+    "gcre_rccl_selftest", "gcre_rccl_collectives", "gcre_join_ahead",
 ]
 
 
@@ -166,6 +166,7 @@ def load_library():
     lib.gcre_uids_free.argtypes = [V]
     lib.gcre_uids_free.restype = None
     lib.gcre_join_uids.argtypes = [V, V, V, V, V, ctypes.POINTER(gcre_join_opts), ctypes.POINTER(gcre_result)]
+    lib.gcre_join_ahead.argtypes = [V, V, V, V, V, ctypes.POINTER(gcre_join_opts)]
     lib.gcre_get_profile.argtypes = [V, ctypes.POINTER(gcre_profile)]
     lib.gcre_process_paths.argtypes = [V, ctypes.POINTER(gcre_pp_input), ctypes.POINTER(gcre_result)]
     lib.gcre_resolve_count_locs.argtypes = [P, I64, P, P, P, I64, P, P]
@@ -466,6 +467,23 @@ class JoinExec:
         self._check(rc)
         return _take_result(self._lib, res)
 
+    def join_ahead(self, uids: Optional["DeviceUids"], paths0: Optional[PathSet] = None, paths1: Optional[PathSet] = None,
+                   paths_res: Optional[PathSet] = None, shard: Optional[Tuple[int, int]] = None,
+                   keep: Optional[Tuple[int, int]] = None, keep_mode: int = 1) -> None:
+        """gcre_join_ahead: register the NEXT join of a sequence.  The join call that follows runs this join's inspector on
+        a stream of its own while its own permutation kernel is in flight; the registered join, called next with the same
+        arguments, then starts at its permutation kernel.  Needs the inspection cache (``set_inspect_cache(True)``)."""
+        if uids is None:
+            self._check(self._lib.gcre_join_ahead(self._h, None, None, None, None, None))
+            return
+        opts = gcre_join_opts(0, 0, 0, 0, None, 0, 0, 0, None, None)
+        if shard is not None:
+            opts.sharded, opts.shard_begin, opts.shard_end = 1, int(shard[0]), int(shard[1])
+        if keep is not None:
+            opts.keep_ranged, opts.keep_begin, opts.keep_end = int(keep_mode), int(keep[0]), int(keep[1])
+        res_h = paths_res._h if paths_res is not None else None
+        self._check(self._lib.gcre_join_ahead(self._h, uids._h, paths0._h, paths1._h, res_h, ctypes.byref(opts)))
+
     def profile(self) -> Dict[str, float]:
         p = gcre_profile()
         self._check(self._lib.gcre_get_profile(self._h, ctypes.byref(p)))
@@ -699,6 +717,9 @@ class ResidentPlan:
         self._pivot: Dict[tuple, DeviceUids] = {}
         # off by default: measured -- the level-4 shard gains 3 %, keeping all of level 2's planes costs more
         self.pivot_shards = os.environ.get("GCRE_PIVOT_SHARDS", "0") == "1"
+        # GCRE_AHEAD=1: every join's inspector runs beside the permutation kernel of the join before it (off by default: it
+        # does not pay; the library honours the same variable)
+        self.ahead = os.environ.get("GCRE_AHEAD", "0") == "1"
         if "4" in self.uids:    # level 2 put the added gene into the (-) half of paths2[loc] when the relation is negative
             self._reduced_args["4"] = (parsed1, np.asarray(lv.data_inds["3"], np.int64) | (rel_neg.astype(np.int64) << 31))
             self.uids["4"].set_reduced(*self._reduced_args["4"])
@@ -838,13 +859,17 @@ class ResidentPlan:
         if self._window is None:
             self._window = self.planned_window()
         n_windows = len(range(0, max(K, 1), self._window))
-        if keep_inspections or n_windows > 1:
+        # inspect-ahead (gcre_join_ahead): every join's inspector runs beside the permutation kernel of the join before it,
+        # into the inspection cache -- which therefore is on for the pass and, unless the caller keeps inspections, forgotten
+        # when the pass ends (nothing of one pass serves the next)
+        ahead = self.ahead and K > 0
+        if keep_inspections or n_windows > 1 or ahead:
             self.ex.set_inspect_cache(True)
             if not keep_inspections:
                 self.ex.drop_inspections()
         elif self._cache_on:
             self.ex.set_inspect_cache(False)
-        self._cache_on = keep_inspections or n_windows > 1
+        self._cache_on = keep_inspections or n_windows > 1 or ahead
         out: Dict[str, JoinResult] = {}
         nulls: Dict[str, list] = {}
         prof: Dict[str, float] = {}
@@ -852,11 +877,21 @@ class ResidentPlan:
             k1 = min(K, k0 + self._window)
             if K > 0:
                 self.ex.set_perm_window(k0, k1)
-            for name in self.names:
+            def spec(name):
+                p0, p1, res = self.operands(name)
+                b, e = self.shard(name, rank, world)
+                by_pivot = self.pivot_sharded(name, world)
+                return (self.pivot_uids(name, rank, world) if by_pivot else self.uids[name], p0, p1, res,
+                        (b, e) if (world > 1 and not by_pivot) else None, self.needed_rows(name, rank, world), self.keep_mode(name))
+
+            for pos, name in enumerate(self.names):
                 p0, p1, res = self.operands(name)
                 b, e = self.shard(name, rank, world)
                 n_ex = self.exchange_count(name, world) if (exchange is not None and d_null_out) else 0
                 by_pivot = self.pivot_sharded(name, world)
+                if ahead and pos + 1 < len(self.names):
+                    u_n, p0_n, p1_n, res_n, shard_n, keep_n, mode_n = spec(self.names[pos + 1])
+                    self.ex.join_ahead(u_n, p0_n, p1_n, res_n, shard=shard_n, keep=keep_n, keep_mode=mode_n)
                 r = self.ex.join(self.pivot_uids(name, rank, world) if by_pivot else self.uids[name], p0, p1, res,
                                  shard=(b, e) if (world > 1 and not by_pivot) else None,
                                  d_null_out=(d_null_out + 4 * k0) if d_null_out else 0,

@@ -247,6 +247,8 @@ struct ExchangeHub {
   }
 };
 
+namespace { struct JoinPlan; }
+
 struct gcre_ctx {
   Geometry g{};
   int device = 0;
@@ -257,6 +259,18 @@ struct gcre_ctx {
   hipStream_t sel_stream = nullptr;
   hipEvent_t ev_sel = nullptr, ev_sel_done = nullptr;
   bool sel_async = true;
+  // Inspect-ahead (gcre_join_ahead, round 4).  The inspector of the NEXT join of a sequence only needs what the current
+  // join's inspector wrote (kept rows, recipe) -- not its permutation kernel -- so it runs on a stream of its own while
+  // that kernel is in flight, into the next join's inspection cache; the next join then starts at its null kernel.
+  hipStream_t insp_stream = nullptr;
+  hipEvent_t ev_insp_done = nullptr;    // recorded on insp_stream when an ahead inspection has queued all its work
+  hipEvent_t ev_insp_main = nullptr;    // recorded on the main stream behind the last inspector that ran there
+  uint32_t* d_max_tot_b = nullptr;      // the flag block of ahead inspections (the null kernel in flight owns d_max_tot)
+  JoinPlan* ahead = nullptr;            // the registered next join, consumed by the next join call
+  bool ahead_on = false;                // GCRE_AHEAD=1 turns gcre_join_ahead on.  Off by default: measured on configs[2], a pass takes
+                                        // 31.5 ms with it and 31.4 without -- the next level's inspector and this level's permutation
+                                        // kernel each fill the GPU, so running them side by side only trades the host-side gaps for
+                                        // contention (26.1 + 9.9 ms of kernel time inside 31.3 ms instead of 23.0 + 6.0)
   SelectState h_sel{};               // where the digit passes' state lands (outlives any one chunk: the copy is asynchronous)
   std::string err;
   int last_code = GCRE_OK;
@@ -302,7 +316,7 @@ struct gcre_ctx {
 
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk, d_rec_segs;
-  DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan, d_excess;
+  DevBuf<uint64_t> d_key, d_wkey, d_doff, d_scan, d_excess, d_excess_b;
   DevBuf<uint32_t> d_dcnt, d_dlist, d_rowz, d_linfo, d_lover, d_dover;
   DevBuf<uint32_t> d_wcases, d_wctrls, d_wrow0, d_wrow1;
 
@@ -1059,9 +1073,16 @@ struct JoinPlan {
   }
 };
 
+void drop_ahead(gcre_ctx* c) {
+  delete c->ahead;
+  c->ahead = nullptr;
+}
+
 void free_uids(gcre_uids* u) {
   if (!u) return;
+  if (u->ctx && u->ctx->ahead && u->ctx->ahead->u == u) drop_ahead(u->ctx);   // a registered next join names this index
   if (u->ctx && u->ctx->stream) (void)hipStreamSynchronize(u->ctx->stream);
+  if (u->ctx && u->ctx->insp_stream) (void)hipStreamSynchronize(u->ctx->insp_stream);
   if (u->ctx) {
     auto& v = u->ctx->live_uids;
     v.erase(std::remove(v.begin(), v.end(), u), v.end());
@@ -1185,7 +1206,10 @@ int ensure_ranges(gcre_ctx* c, const gcre_uids& u) {
   return GCRE_OK;
 }
 
-int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
+// inspect_only (gcre_join_ahead): the mask-independent half of the join -- expansion, inspector, kept rows, recipe, flags, top-k
+// winners -- on the inspection stream, into the join index's inspection cache; nothing of the permutation kernel's (no maxima,
+// no count planes, no results).  The join proper then replays it and starts at its null kernel.
+int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_only = false) {
   // the join sees the permutation window (all permutations unless gcre_set_perm_window narrowed it): K, the slice of
   // the transposed masks, of the masks (row stride stays the full Kpad) and of the maxima
   Geometry g = c->g;
@@ -1196,7 +1220,15 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   const uint32_t* const w_masks = c->d_masks ? c->d_masks + c->win_k0 : nullptr;
   const uint32_t* const w_mt = c->d_mt ? c->d_mt + (size_t)(c->win_k0 / kSparseTile) * (size_t)(64 * g.Wp + 1) * 64 : nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
-  std::memset(out, 0, sizeof *out);
+  if (out) std::memset(out, 0, sizeof *out);
+  // the registered next join (gcre_join_ahead) belongs to THIS call: taken here, inspected below once this join's own
+  // kernels are in flight, dropped on every road out
+  std::unique_ptr<JoinPlan> ahead_plan;
+  if (!inspect_only) {
+    ahead_plan.reset(c->ahead);
+    c->ahead = nullptr;
+  }
+  uint32_t* const flagblk = inspect_only ? c->d_max_tot_b : c->d_max_tot;
   if (!c->have_table) return fail(c, GCRE_ERR_ASSERT, "value table not set");
   if (g.K > 0 && !c->have_perms) return fail(c, GCRE_ERR_ASSERT, "permuted cases not set");
   if (c->top_k < 1) return fail(c, GCRE_ERR_ARG, "top_k must be >= 1");
@@ -1232,6 +1264,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     ikey.top_k = c->top_k;
     ikey.null_kernel = c->null_kernel;
     replay = u.insp_valid && u.insp_key == ikey && (!keep || jp.res->version == u.insp_res_ver);
+    if (inspect_only && replay) return GCRE_OK;   // already inspected (a later permutation window, kept inspections)
     if (!replay) {
       for (auto& ci : u.insp) {   // the buffers stay and serve the new chunks in turn
         ci.inspected = ci.with_lists = ci.flags_valid = ci.win_valid = false;
@@ -1240,6 +1273,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       u.insp_key = ikey;
     }
     u.insp_valid = false;   // until this call completes
+  } else if (inspect_only) {
+    return GCRE_OK;   // no inspection cache, nothing to inspect ahead into
   } else if (u.insp_valid || !u.insp.empty()) {
     for (auto& ci : u.insp) ci.release();
     u.insp.clear();
@@ -1270,9 +1305,22 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
   sb = std::max<int64_t>(0, std::min(sb, P));
   se = std::max(sb, std::min(se, P));
 
-  hipStream_t st = c->stream;
+  hipStream_t st = inspect_only ? c->insp_stream : c->stream;
   const int Kpad = g.Kpad;
-  if (Kpad > 0) HIP_TRY(c, hipMemsetAsync(w_null, 0, (size_t)Kpad * 4, st));
+  if (inspect_only) {
+    // behind the last inspector that ran on the main stream (its kept rows and recipe are this one's operands)
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_insp_main, 0));
+  } else {
+    // behind an inspection that ran ahead on its own stream (a no-op when there was none)
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_insp_done, 0));
+    if (Kpad > 0) HIP_TRY(c, hipMemsetAsync(w_null, 0, (size_t)Kpad * 4, st));
+  }
+  bool ahead_started = false;
+  auto run_ahead = [&]() -> int {
+    if (ahead_started || !ahead_plan) return GCRE_OK;
+    ahead_started = true;
+    return run_join(c, *ahead_plan, nullptr, true);
+  };
 
   const NullConfig cfg = null_config(g.method, g.K);
   // ---- thresholds shared across devices: the maxima so far go out, the merged ones come back (gcre_join_opts.exchange) ----
@@ -1290,7 +1338,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     return GCRE_OK;
   };
   std::vector<Candidate> cands;
-  c->prof = gcre_profile{};
+  if (!inspect_only) c->prof = gcre_profile{};   // (an ahead inspection's host times and replays count with the join it ran beside)
   double select_ms = 0, select_wait_ms = 0;
   bool keep_planes_done = false;
   int64_t keep_planes_lo = 0, keep_planes_hi = 0;
@@ -1378,7 +1426,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     auto collect_ie_stat = [&]() {
       if (!ie_stat_pending) return;
       uint32_t v = 0;
-      if (hipMemcpyAsync(&v, c->d_max_tot + 3, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+      if (hipMemcpyAsync(&v, flagblk + 3, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
         c->prof.ie_lookup_tiles += v;
       ie_stat_pending = false;
     };
@@ -1406,6 +1454,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
       r_hi = std::min<int64_t>(u.n_uids, (int64_t)(std::lower_bound(pi.begin(), pi.end(), last) - pi.begin()));
     }
     if (want_ie) {
+     if (inspect_only) {
+      // count planes are the permutation kernel's business: the join proper looks after them (and decides, from what it
+      // then finds, where its rows' planes go); the inspector only needs to know which rows the join adds
+      red = hinted ? u.red : jp.p1;
+      have_pz = have_p0 = true;
+     } else {
       if (int rc = prepare_z()) return rc;
       have_p0 = planes_cover(c, jp.p0, r_lo, r_hi);        // a kept join left them behind
       if (!have_p0 && recipe_operands(c, jp.p0, &rec_a, &rec_z)) {
@@ -1434,20 +1488,23 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         have_p0 = planes_current(c, jp.p0);
       }
       if (!have_p0 || !have_pz) want_ie = false;   // the planes do not fit in device memory: delta streaming (gcre_sparse.hip)
+     }
+      // (an ahead inspection has its own excess rows: the join in flight on the main stream may still be writing its own)
+      auto& exbuf = inspect_only ? c->d_excess_b : c->d_excess;
       if (want_ie && hinted) {
         // the hint is checked without reading paths1 per joined path: once per distinct uid range here (the reduced
         // row lies inside paths1[loc]; what paths1[loc] has beyond it is collected per range), and per joined path in
         // k_stats_ie (that excess lies inside paths0[idx])
         if (int rc = ensure_ranges(c, u)) return rc;
         const size_t ewords = (size_t)std::max<int64_t>(u.n_ranges, 1) * g.S;
-        HIP_TRY(c, c->d_excess.reserve(ewords));
-        HIP_TRY(c, hipMemsetAsync(c->d_excess.p, 0, ewords * 8, st));
-        HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, 32, st));
+        HIP_TRY(c, exbuf.reserve(ewords));
+        HIP_TRY(c, hipMemsetAsync(exbuf.p, 0, ewords * 8, st));
+        HIP_TRY(c, hipMemsetAsync(flagblk, 0, 32, st));
         // its verdict lands in word 6 of the flag block, which the chunks leave alone: it is read with the first
         // chunk's flags (no round trip of its own); a reduced row that is not even part of the row it stands for sends
         // that chunk, and the join, back to paths1 itself like any other broken hint
         HIP_TRY(c, launch_range_union(jp.p1->d_rows, red->d_rows, u.d_red_index, u.d_pair_range, u.d_pair_loc, u.n_pairs, g.S,
-                                      g.Wp, g.method, c->d_excess.p, c->d_max_tot + 6, st));
+                                      g.Wp, g.method, exbuf.p, flagblk + 6, st));
       }
       if (want_ie && keep) {
         // carriers of a joined row <= carriers(paths0 row) + carriers(added row); <= padded patient count
@@ -1477,7 +1534,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             want_out = plane_bytes(c, jp.res->nrows, out_groups) <= c->planes_out_max || use_rec || jp.res->planes_wanted;
           }
         }
-        if (want_out) {
+        if (inspect_only) {
+          // (the join proper allocates -- or drops -- the kept rows' planes)
+        } else if (want_out) {
           res_planes = alloc_planes(c, jp.res, out_groups);
           res_planes_ok = res_planes;
         } else {
@@ -1602,9 +1661,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         if (use_sparse || use_ie) {
           collect_ie_stat();
           // flags of this chunk; the long-list counter (word 4) runs on across the chunks of a join that keeps a recipe
-          HIP_TRY(c, hipMemsetAsync(c->d_max_tot, 0, (rcp && recipe_started) ? 16 : 24, st));   // words 6, 7: the join's
+          HIP_TRY(c, hipMemsetAsync(flagblk, 0, (rcp && recipe_started) ? 16 : 24, st));   // words 6, 7: the join's
           recipe_started = recipe_started || rcp != nullptr;
-          sa.max_tot = c->d_max_tot;
+          sa.max_tot = flagblk;
           HIP_TRY(c, hold(c->d_dcnt, (size_t)n * g.method));
           sa.dcnt = c->d_dcnt.p;
         }
@@ -1620,9 +1679,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, hold(c->d_dover, std::max<size_t>(c->d_dover.cap, nl * 2 + over_slack)));
           sa.pz = red->d_rows;
           sa.zindex = hinted ? u.d_red_index : nullptr;
-          sa.excess = hinted ? c->d_excess.p : nullptr;
+          sa.excess = hinted ? (inspect_only ? c->d_excess_b.p : c->d_excess.p) : nullptr;
           sa.range_of = hinted ? u.d_range_of : nullptr;
-          sa.bad = c->d_max_tot + 1;
+          sa.bad = flagblk + 1;
           sa.ie_bias = 8;
           sa.ie_rule = g.method == 1 ? 1 : 0;   // the bound filter and the quad kernel want overlap lists
           if (rcp) {   // straight into the recipe of the kept set (absolute row = cb + i)
@@ -1641,7 +1700,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             sa.over = c->d_dover.p;
             sa.over_cap = (uint32_t)std::min<size_t>(c->d_dover.cap - 16, 0xfffffff0u);
           }
-          sa.ov_count = c->d_max_tot + 4;
+          sa.ov_count = flagblk + 4;
           sa.zoff = (uint32_t)(64 * g.Wp) << 8;
           if (!hit) HIP_TRY(c, launch_stats_ie(sa, g.method, st));
           // a kept row's carrier total bounds every count of it: the next level loads only the plane groups that can be non-zero
@@ -1651,6 +1710,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         }
         if (!hit) {
           HIP_TRY(c, hipEventRecord(e1, st));
+          if (!inspect_only) HIP_TRY(c, hipEventRecord(c->ev_insp_main, st));
           c->ev_stats.emplace_back(e0, e1);
           if (ci) {
             ci->inspected = true;
@@ -1684,7 +1744,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (hit) {
             std::memcpy(flags, ci->flags, sizeof flags);   // as the inspector left them (no round trip)
           } else {
-            HIP_TRY(c, hipMemcpyAsync(flags, c->d_max_tot, 32, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipMemcpyAsync(flags, flagblk, 32, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
           }
           if ((size_t)flags[4] + 16 > (rcp ? rcp->over.cap : c->d_dover.cap)) {
@@ -1722,6 +1782,18 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           if (ci && !hit) {
             std::memcpy(ci->flags, flags, sizeof flags);
             ci->flags_valid = true;
+          }
+          if (inspect_only) {   // nothing of the permutation kernel's; the chunk's winners are collected below
+            join_max_tot = std::max(join_max_tot, flags[0]);
+            if (sel_begun && scored && !sel_done) {
+              HIP_TRY(c, hipStreamSynchronize(sel_on));
+              uint32_t nsel = 0;
+              if (int rc = select_finish(c, s0, s1 - s0, c->top_k, sel_state, &nsel, sel_on)) return rc;
+              if (int rc = queue_winners(s0, nsel, win, sel_on)) return rc;
+              sel_done = true;
+            }
+            ran_sparse = true;
+            break;
           }
           const int64_t nseg_est = std::max<int64_t>(uids_in(cb, n), 1);
           if (c->null_kernel == 0 && scored) {
@@ -1811,7 +1883,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           while (ia.waves_per_xcd > 4 && n * ie_tile_factor < (int64_t)8 * ia.waves_per_xcd * 32)
             ia.waves_per_xcd = std::max(4, (ia.waves_per_xcd / 2 / 4) * 4);
           c->prof.inspect_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
-          ia.stats = c->d_max_tot + 3;   // 4th word of the flag block: zeroed with it before k_stats ran
+          ia.stats = flagblk + 3;   // 4th word of the flag block: zeroed with it before k_stats ran
           static uint64_t* d_timing = nullptr;   // diagnostics builds only (-DGCRE_IE_TIMING), GCRE_IE_TIMING=1
           const bool timing = std::getenv("GCRE_IE_TIMING") != nullptr;
           if (timing) {
@@ -1919,6 +1991,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
             if (int rc = queue_winners(s0, nsel, win, sel_on)) return rc;
             sel_done = true;
           }
+          // This join's kernels are in flight: the registered next join's inspector runs beside them (on its own stream,
+          // into its own buffers; the host waits for ITS flags while the GPU works on both).  Only behind the last chunk,
+          // and only when the selection scratch is free of this join's pending copies (own selection stream, or winners
+          // that came from the cache)
+          if (next >= sg.e && &sg == &segs.back() && (sel_on != st || !sel_begun))
+            if (int rc = run_ahead()) return rc;
           if (timing) {
             uint64_t tmv[8] = {0};
             HIP_TRY(c, hipMemcpyAsync(tmv, d_timing, 64, hipMemcpyDeviceToHost, st));
@@ -1967,7 +2045,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
         }
         if (!scored) continue;
 
-        if (g.K > 0 && use_sparse) do {
+        if (g.K > 0 && use_sparse && !inspect_only) do {
           // inspector (once per chunk, shared by all permutation tiles): per joined path the bits paths1 adds
           // on top of paths0 -> offsets by a device scan of the counts k_stats left, entries by k_delta_fill
           if (int rc = ensure_lists(c, jp.p0)) return rc;
@@ -1979,7 +2057,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           HIP_TRY(c, launch_scan_u32_u64(c->d_dcnt.p, nl, c->d_doff.p, c->d_scan.p, st));
           uint32_t max_tot = 0;
           uint64_t n_delta = 0;
-          HIP_TRY(c, hipMemcpyAsync(&max_tot, c->d_max_tot, 4, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipMemcpyAsync(&max_tot, flagblk, 4, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipMemcpyAsync(&n_delta, c->d_doff.p + nl, 8, hipMemcpyDeviceToHost, st));
           HIP_TRY(c, hipStreamSynchronize(st));
           if (hit) max_tot = ci->flags[0];   // the flag block was cleared for this window; the inspector's value was kept
@@ -2045,7 +2123,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           c->prof.null_alg_bytes += alg_bytes(cb, n);
           ran_sparse = true;
         } while (false);
-        if (g.K > 0 && !ran_sparse) {
+        if (g.K > 0 && !ran_sparse && !inspect_only) {
           NullArgs na{};
           na.p0 = (const uint32_t*)jp.p0->d_rows;
           na.p1 = (const uint32_t*)jp.p1->d_rows;
@@ -2111,10 +2189,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
           ci->win_valid = true;
         }
         select_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count();
-        c->prof.paths += s1 - s0;
+        if (!inspect_only) c->prof.paths += s1 - s0;
       }
     }
-    collect_ie_stat();
+    if (!inspect_only) collect_ie_stat();
     if (rcp && want_ie && !recipe_broken) {
       // the recipe names its operands by id and row version: the set paths0 was, and the rows the join really added
       rcp->a_id = jp.p0->id;
@@ -2139,6 +2217,12 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
     if (ie_ran && have_p0) c->prof.ie_plane_joins++;
   }
 
+  if (inspect_only) {
+    // everything this inspection queued is behind this event: the join proper waits for it on the main stream
+    HIP_TRY(c, hipEventRecord(c->ev_insp_done, st));
+    return GCRE_OK;
+  }
+  if (int rc = run_ahead()) return rc;   // (joins that took another road: no overlap, same result)
   if (keep_planes_done) {
     // the kept rows leave with their count planes: the next level's N0 (gcre_ie.hip)
     jp.res->planes_epoch = c->mask_epoch;
@@ -2277,11 +2361,16 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
 
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&c->sel_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&c->insp_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_insp_done, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_insp_main, hipEventDisableTiming) == hipSuccess;
+  if (const char* e = std::getenv("GCRE_AHEAD")) c->ahead_on = std::atoi(e) != 0;
   ok = ok && hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_sel_done, hipEventDisableTiming) == hipSuccess;
   if (const char* e = std::getenv("GCRE_SELECT_STREAM")) c->sel_async = std::atoi(e) != 0;
   ok = ok && hipMalloc((void**)&c->d_case_mask, (size_t)g.Wp * 8) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_max_tot, 32) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_max_tot_b, 32) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_queue, 8 * 16 * 4) == hipSuccess;
   if (ok && g.Kpad > 0) {
     ok = hipMalloc((void**)&c->d_masks, (size_t)2 * g.Wp * g.Kpad * 4) == hipSuccess;
@@ -2306,6 +2395,8 @@ void gcre_destroy(gcre_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->insp_stream) (void)hipStreamSynchronize(c->insp_stream);
+  drop_ahead(c);
   // path sets and join indices the caller did not free: their rows, lists, count planes, recipes and segment tables go
   // with the context (their handles are invalid from here on, include/gcre_hip.h)
   while (!c->live_uids.empty()) free_uids(c->live_uids.back());
@@ -2315,7 +2406,7 @@ void gcre_destroy(gcre_ctx* c) {
     for (const gcre_pathset* ps : sets) gcre_pathset_free(const_cast<gcre_pathset*>(ps));
   }
   for (void* p : {(void*)c->d_case_mask, (void*)c->d_masks, (void*)c->d_t32, (void*)c->d_dvt, (void*)c->d_dmax,
-                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot, (void*)c->d_queue, (void*)c->d_ladder})
+                  (void*)c->d_null, (void*)c->d_mt, (void*)c->d_max_tot, (void*)c->d_max_tot_b, (void*)c->d_queue, (void*)c->d_ladder})
     if (p) (void)hipFree(p);
   for (auto* b : {&c->d_row0, &c->d_row1, &c->d_tot, &c->d_cases, &c->d_ctrls, &c->d_sel, &c->d_small, &c->d_chunk,
                   &c->d_rec_segs, &c->d_wcases, &c->d_wctrls, &c->d_wrow0, &c->d_wrow1})
@@ -2326,6 +2417,7 @@ void gcre_destroy(gcre_ctx* c) {
   c->d_doff.release();
   c->d_scan.release();
   c->d_excess.release();
+  c->d_excess_b.release();
   c->d_dcnt.release();
   c->d_dlist.release();
   c->d_rowz.release();
@@ -2337,6 +2429,9 @@ void gcre_destroy(gcre_ctx* c) {
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->sel_stream) (void)hipStreamSynchronize(c->sel_stream);
   if (c->sel_stream) (void)hipStreamDestroy(c->sel_stream);
+  if (c->insp_stream) (void)hipStreamDestroy(c->insp_stream);
+  if (c->ev_insp_done) (void)hipEventDestroy(c->ev_insp_done);
+  if (c->ev_insp_main) (void)hipEventDestroy(c->ev_insp_main);
   if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
   if (c->ev_sel_done) (void)hipEventDestroy(c->ev_sel_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2670,6 +2765,8 @@ void gcre_pathset_free(gcre_pathset* ps) {
   if (ps->ctx) {
     (void)hipSetDevice(ps->ctx->device);
     if (ps->ctx->stream) (void)hipStreamSynchronize(ps->ctx->stream);
+    if (ps->ctx->insp_stream) (void)hipStreamSynchronize(ps->ctx->insp_stream);
+    if (ps->ctx->ahead && (ps->ctx->ahead->p0 == ps || ps->ctx->ahead->p1 == ps || ps->ctx->ahead->res == ps)) drop_ahead(ps->ctx);
   }
   if (ps->d_rows) (void)hipFree(ps->d_rows);
   drop_lists(ps);   // lists, and the plane buffer goes to the context's pool
@@ -2755,6 +2852,22 @@ int gcre_join_uids(gcre_ctx* c, const gcre_uids* uids, const gcre_pathset* paths
   int rc = run_join(c, jp, out);
   if (rc != GCRE_OK) gcre_result_free(out);
   return rc;
+}
+
+int gcre_join_ahead(gcre_ctx* c, const gcre_uids* uids, const gcre_pathset* paths0, const gcre_pathset* paths1,
+                    gcre_pathset* res, const gcre_join_opts* opts) {
+  if (!c) return GCRE_ERR_ARG;
+  drop_ahead(c);
+  if (!uids) return GCRE_OK;   // (cancels a registration)
+  if (!c->ahead_on || !c->insp_cache) return GCRE_OK;   // nothing to inspect ahead into: the next join simply runs whole
+  if (uids->ctx != c || !paths0 || !paths1 || paths0->ctx != c || paths1->ctx != c || (res && res->ctx != c))
+    return fail(c, GCRE_ERR_ARG, "uids / path set do not belong to this context");
+  c->ahead = new JoinPlan{uids, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
+                          opts ? opts->shard_end : 0, nullptr};
+  c->ahead->take(opts);
+  c->ahead->exchanges = 0;       // an inspection exchanges nothing
+  c->ahead->exchange = nullptr;
+  return GCRE_OK;
 }
 
 void gcre_result_free(gcre_result* r) {

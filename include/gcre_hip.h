@@ -171,6 +171,20 @@ int gcre_uids_set_reduced(gcre_uids* uids, const gcre_pathset* reduced, const in
 int gcre_join_uids(gcre_ctx* ctx, const gcre_uids* uids, const gcre_pathset* paths0, const gcre_pathset* paths1,
                    gcre_pathset* res, const gcre_join_opts* opts, gcre_result* out);
 
+/* Inspect-ahead.  A join is an inspector (expansion, real-label statistics and observed scores, kept rows, the lists the
+ * permutation kernel streams, top-k selection: nothing of it depends on the permutation masks) followed by its permutation
+ * kernel, and the inspector of the NEXT join of a sequence (src/wrapper.cpp:225-276) only reads what THIS join's inspector
+ * wrote -- the kept rows -- not what its permutation kernel computes.  gcre_join_ahead registers the next join: the following
+ * gcre_join / gcre_join_uids call on the context runs that join's inspector on a stream of its own as soon as its own kernels
+ * are in flight, into the registered join index's inspection cache, and the registered join -- the same index, operands, kept
+ * set and opts, called next -- starts at its permutation kernel.  Needs the inspection cache (gcre_set_inspect_cache(ctx, 1)
+ * for the pass) and GCRE_AHEAD=1 in the environment: it is OFF by default -- measured, it does not pay (both kernels fill the
+ * GPU) -- and without either the call registers nothing and every join runs whole.  uids = NULL
+ * cancels a registration; freeing a registered object cancels it too.  Results never depend on it. */
+int gcre_join_ahead(gcre_ctx* ctx, const gcre_uids* uids, const gcre_pathset* paths0, const gcre_pathset* paths1,
+                    gcre_pathset* res, const gcre_join_opts* opts);
+
+
 int gcre_get_profile(const gcre_ctx* ctx, gcre_profile* out);
 
 /*

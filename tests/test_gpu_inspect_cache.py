@@ -189,3 +189,33 @@ def test_kept_inspections_without_permutations_and_with_a_sentinel(method):
             assert all(len(got[name].null) == 0 for name, _ in LEVELS[:3])
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize("method", ["method1", "method2"])
+@pytest.mark.parametrize("kernel,chunk,window", [("", "", ""), ("ie", "900", ""), ("ie", "", "1"), ("sparse", "", ""), ("dense", "", "")])
+def test_inspect_ahead_gives_the_same_results(method, kernel, chunk, window, monkeypatch):
+    """GCRE_AHEAD=1 (gcre_join_ahead): every join's inspector runs on a stream of its own beside the permutation kernel of the
+    join before it, into the next join's inspection cache; the next join starts at its null kernel.  Off by default (it does not
+    pay: DESIGN.md), exact like everything else: single and several chunks per join, two permutation windows, the kernel forms
+    that do not run the inclusion-exclusion inspector, a sharded pass."""
+    monkeypatch.setenv("GCRE_AHEAD", "1")
+    for k, v in (("GCRE_NULL_KERNEL", kernel), ("GCRE_CHUNK_PATHS", chunk), ("GCRE_WINDOW_TILES", window)):
+        if v:
+            monkeypatch.setenv(k, v)
+    p = make_problem(90, 330, 61, 70, 2300, 5, method=method, top_k=13, seed=77)
+    want = oracle.process_paths(p, order="canonical", nthreads=4)
+    plan = api.ResidentPlan(p)
+    try:
+        assert plan.ahead
+        for _ in range(2):                     # the second pass starts from forgotten inspections again
+            got = plan.run()
+            for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4), ("5", 5)):
+                assert_same_result(got[name], want[f"lst{lvl}"])
+        if not chunk and kernel in ("", "ie"):
+            assert plan.last_profile["inspect_replays"] >= 4     # levels 1b..5 started at their null kernels
+        parts = [plan.run(rank, 3) for rank in range(3)]         # shards: the ahead inspection carries the shard's key
+        for name, lvl in (("1b", 1), ("4", 4), ("5", 5)):
+            null = np.maximum.reduce([q[name].null for q in parts])
+            assert np.array_equal(null.view(np.uint32), want[f"lst{lvl}"].null.view(np.uint32)), (name,)
+    finally:
+        plan.close()
