@@ -140,6 +140,51 @@ inline double key_to_score(uint64_t k) {
 
 inline size_t tri(size_t t) { return t * (t + 1) / 2; }
 
+// Dense int matrix -> packed bit rows ON THE HOST, before anything crosses PCIe (round 4).  What R hands the shim is hundreds
+// of MB of 4-byte ints that carry one bit each (340 MB of genotypes twice and 200 MB of permutation labels at configs[2]):
+// pageable host memory goes up at ~10 GB/s, so uploading the ints and packing them on the device cost the one-shot call more
+// than its kernels.  Packed here they are 1/32 of that.  out[r][w] (stride `stride` words) gets bit b of word w set iff
+// pred(value of (r, 64 w + b), 64 w + b).  Threads own whole word columns (column-major input: 64 consecutive columns are
+// streamed once each, the word column is accumulated in a buffer that stays in cache) or row blocks (row-major input).
+template <typename Pred>
+void pack_bits_host(const int32_t* data, int64_t nrow, int ncol, bool col_major, uint64_t* out, size_t stride, Pred pred) {
+  const int W = (ncol + 63) / 64;
+  if (nrow <= 0 || W <= 0) return;
+  unsigned T = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = std::getenv("GCRE_PACK_THREADS")) T = (unsigned)std::max(1, std::atoi(e));
+  if ((double)nrow * ncol < 4e6) T = 1;
+  auto work = [&](unsigned t) {
+    if (col_major) {
+      std::vector<uint64_t> acc((size_t)nrow);
+      for (int w = (int)t; w < W; w += (int)T) {
+        std::fill(acc.begin(), acc.end(), 0);
+        const int q1 = std::min(ncol, (w + 1) * 64);
+        for (int q = w * 64; q < q1; q++) {
+          const int32_t* col = data + (size_t)q * (size_t)nrow;
+          const uint64_t bit = uint64_t(1) << (q & 63);
+          for (int64_t r = 0; r < nrow; r++) acc[(size_t)r] |= pred(col[r], q) ? bit : 0;
+        }
+        for (int64_t r = 0; r < nrow; r++) out[(size_t)r * stride + (size_t)w] = acc[(size_t)r];
+      }
+    } else {
+      const int64_t r0 = nrow * t / T, r1 = nrow * (t + 1) / T;
+      for (int64_t r = r0; r < r1; r++) {
+        const int32_t* row = data + (size_t)r * (size_t)ncol;
+        for (int w = 0; w < W; w++) {
+          uint64_t v = 0;
+          const int q1 = std::min(ncol, (w + 1) * 64);
+          for (int q = w * 64; q < q1; q++) v |= pred(row[q], q) ? uint64_t(1) << (q & 63) : 0;
+          out[(size_t)r * stride + (size_t)w] = v;
+        }
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+}
+
 // GCRE_HOST_TIMING=1: wall time of the host-side steps around the kernels (stderr)
 struct HostTimer {
   const char* what;
@@ -313,6 +358,9 @@ struct gcre_ctx {
   // permutation window [win_k0, win_k0 + win_K): what a join scores.  The whole range by default; gcre_set_perm_window
   // narrows it so that the count planes of the kept sets (one per 2048-permutation tile) fit in device memory
   int win_k0 = 0, win_K = 0;
+  int win_K_nominal = 0;   // the largest window since the masks were set: whether a kept set leaves with planes or with a recipe
+                           // is decided for THAT size, so that a short last window does not flip the decision (and hipMalloc
+                           // gigabytes of planes for one window: 120-460 ms on a fresh context)
 
   // per-join scratch
   DevBuf<uint32_t> d_row0, d_row1, d_tot, d_cases, d_ctrls, d_sel, d_small, d_chunk, d_rec_segs;
@@ -561,6 +609,7 @@ int build_transposed_masks(gcre_ctx* c) {
   c->mask_epoch++;   // every count plane built so far belongs to the old masks
   c->win_k0 = 0;
   c->win_K = g.K;
+  c->win_K_nominal = 0;
   return GCRE_OK;
 }
 
@@ -1531,7 +1580,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
             rcp->release();
             rcp = nullptr;
           } else {
-            want_out = plane_bytes(c, jp.res->nrows, out_groups) <= c->planes_out_max || use_rec || jp.res->planes_wanted;
+            // (sized for the nominal window: the same answer in every window of a run)
+            const size_t nkt_nom = (size_t)((std::max(c->win_K, c->win_K_nominal) + kSparseTile - 1) / kSparseTile);
+            const size_t nominal = (size_t)std::max<int64_t>(jp.res->nrows, 1) * g.method * nkt_nom * (size_t)out_groups * 1024;
+            want_out = nominal <= c->planes_out_max || use_rec || jp.res->planes_wanted;
           }
         }
         if (inspect_only) {
@@ -2533,6 +2585,37 @@ int gcre_set_perm_cases(gcre_ctx* c, const int32_t* perms, int nrow, int ncol, i
   if (nrow < g.K && !c->quiet)
     std::printf("  ** WARN not enough permuted cases, some will be reused to match iterations - hope this is for testing!\n");
   const int used = std::min(nrow, g.K);
+  static const bool device_pack = std::getenv("GCRE_DEVICE_PACK") && std::atoi(std::getenv("GCRE_DEVICE_PACK")) != 0;
+  if (!device_pack) {
+    // setPermutedCases (join_base.cpp:85-125) on the host: mask_r = case_mask XOR flipped_r, flipped where the input is
+    // not 1 (:103-104); cases are the first n_cases columns (:50-54).  Only the rows that are used are packed (a column-major
+    // matrix keeps its row stride); the packed masks take the road of gcre_set_perm_masks (row reuse included).
+    HostTimer hp("pack permutations (host)");
+    std::vector<uint64_t> packed((size_t)used * g.W, 0);
+    const int n_cases = g.n_cases;
+    if (col_major) {
+      // columns of the full matrix are nrow long: pack all of its rows column block by column block, keep the first `used`
+      if (used == nrow) {
+        pack_bits_host(perms, nrow, ncol, true, packed.data(), (size_t)g.W, [n_cases](int32_t v, int q) { return (v != 1) != (q < n_cases); });
+      } else {
+        std::vector<uint64_t> all((size_t)nrow * g.W, 0);
+        pack_bits_host(perms, nrow, ncol, true, all.data(), (size_t)g.W, [n_cases](int32_t v, int q) { return (v != 1) != (q < n_cases); });
+        std::memcpy(packed.data(), all.data(), packed.size() * 8);
+      }
+    } else {
+      pack_bits_host(perms, used, ncol, false, packed.data(), (size_t)g.W, [n_cases](int32_t v, int q) { return (v != 1) != (q < n_cases); });
+    }
+    uint64_t* d_in = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_in, packed.size() * 8));
+    hipError_t e = hipMemcpyAsync(d_in, packed.data(), packed.size() * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_masks_from_words(d_in, used, g, c->d_masks, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_in);
+    if (e != hipSuccess) return fail(c, GCRE_ERR_DEVICE, std::string("set_perm_cases: ") + hipGetErrorString(e));
+    if (int rc = build_transposed_masks(c)) return rc;
+    c->have_perms = true;
+    return GCRE_OK;
+  }
   std::vector<int32_t> rows;
   const int32_t* src = perms;   // row-major: the first `used` rows are contiguous
   if (col_major) {              // R matrix: gather the rows we need
@@ -2619,6 +2702,7 @@ int gcre_set_perm_window(gcre_ctx* c, int k0, int k1) {
     c->win_K = k1 - k0;
     c->mask_epoch++;   // count planes hold the tiles of one window
   }
+  c->win_K_nominal = std::max(c->win_K_nominal, k1 - k0);
   return GCRE_OK;
 }
 
@@ -2677,13 +2761,25 @@ gcre_pathset* gcre_pathset_from_dense(gcre_ctx* c, const int32_t* data, int64_t 
   }
   gcre_pathset* ps = new_pathset(c, nrow, true);
   if (!ps || nrow == 0 || ncol == 0) return ps;
-  int32_t* d_in = nullptr;
-  const size_t bytes = (size_t)nrow * ncol * 4;
-  hipError_t e = hipMalloc((void**)&d_in, bytes);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_in, data, bytes, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = launch_pack_dense(d_in, nrow, ncol, col_major, ps->d_rows, c->g.S, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (d_in) (void)hipFree(d_in);
+  hipError_t e = hipSuccess;
+  static const bool device_pack = std::getenv("GCRE_DEVICE_PACK") && std::atoi(std::getenv("GCRE_DEVICE_PACK")) != 0;
+  if (!device_pack) {
+    // PathSet::load (gcre_paths.h:56-70) on the host: bit c of row r set iff data[r][c] != 0, (+) half only -- then the
+    // packed rows go up (1/32 of the ints; GCRE_DEVICE_PACK=1: the ints go up and k_pack_dense packs them, as before round 4)
+    HostTimer hp("pack genotypes (host)");
+    std::vector<uint64_t> packed((size_t)nrow * c->g.S, 0);
+    pack_bits_host(data, nrow, ncol, col_major != 0, packed.data(), (size_t)c->g.S, [](int32_t v, int) { return v != 0; });
+    e = hipMemcpyAsync(ps->d_rows, packed.data(), packed.size() * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `packed` is a local
+  } else {
+    int32_t* d_in = nullptr;
+    const size_t bytes = (size_t)nrow * ncol * 4;
+    e = hipMalloc((void**)&d_in, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, data, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_pack_dense(d_in, nrow, ncol, col_major, ps->d_rows, c->g.S, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d_in) (void)hipFree(d_in);
+  }
   if (e != hipSuccess) {
     fail(c, GCRE_ERR_DEVICE, std::string("pathset_from_dense: ") + hipGetErrorString(e));
     gcre_pathset_free(ps);
