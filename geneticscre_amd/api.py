@@ -470,9 +470,11 @@ class JoinExec:
     def join_ahead(self, uids: Optional["DeviceUids"], paths0: Optional[PathSet] = None, paths1: Optional[PathSet] = None,
                    paths_res: Optional[PathSet] = None, shard: Optional[Tuple[int, int]] = None,
                    keep: Optional[Tuple[int, int]] = None, keep_mode: int = 1) -> None:
-        """gcre_join_ahead: register the NEXT join of a sequence.  The join call that follows runs this join's inspector on
-        a stream of its own while its own permutation kernel is in flight; the registered join, called next with the same
-        arguments, then starts at its permutation kernel.  Needs the inspection cache (``set_inspect_cache(True)``)."""
+        """gcre_join_ahead: register a LATER join of a sequence (call it once per later join, in order; ``None`` cancels).
+        The join call that follows inspects and launches every registered join in turn once its own work is queued -- the
+        inspectors on a stream of their own, beside the permutation kernels of the joins before them -- and the registered
+        joins, called afterwards with the same arguments, only collect their results.  Needs the inspection cache
+        (``set_inspect_cache(True)``) and GCRE_AHEAD=1."""
         if uids is None:
             self._check(self._lib.gcre_join_ahead(self._h, None, None, None, None, None))
             return
@@ -889,9 +891,15 @@ class ResidentPlan:
                 b, e = self.shard(name, rank, world)
                 n_ex = self.exchange_count(name, world) if (exchange is not None and d_null_out) else 0
                 by_pivot = self.pivot_sharded(name, world)
-                if ahead and pos + 1 < len(self.names):
-                    u_n, p0_n, p1_n, res_n, shard_n, keep_n, mode_n = spec(self.names[pos + 1])
-                    self.ex.join_ahead(u_n, p0_n, p1_n, res_n, shard=shard_n, keep=keep_n, keep_mode=mode_n)
+                if ahead and pos == 0:
+                    # the chain: every later level of this window, in order, up to the first one that exchanges thresholds
+                    # with other ranks inside its join (that one, and what reads its rows, runs in its own call)
+                    self.ex.join_ahead(None)
+                    for later in self.names[1:]:
+                        if exchange is not None and d_null_out and self.exchange_count(later, world) > 0:
+                            break
+                        u_n, p0_n, p1_n, res_n, shard_n, keep_n, mode_n = spec(later)
+                        self.ex.join_ahead(u_n, p0_n, p1_n, res_n, shard=shard_n, keep=keep_n, keep_mode=mode_n)
                 r = self.ex.join(self.pivot_uids(name, rank, world) if by_pivot else self.uids[name], p0, p1, res,
                                  shard=(b, e) if (world > 1 and not by_pivot) else None,
                                  d_null_out=(d_null_out + 4 * k0) if d_null_out else 0,

@@ -310,8 +310,10 @@ struct gcre_ctx {
   hipStream_t insp_stream = nullptr;
   hipEvent_t ev_insp_done = nullptr;    // recorded on insp_stream when an ahead inspection has queued all its work
   hipEvent_t ev_insp_main = nullptr;    // recorded on the main stream behind the last inspector that ran there
+  hipEvent_t ev_tail = nullptr;         // behind a join's own result copies, before the chain it launches
   uint32_t* d_max_tot_b = nullptr;      // the flag block of ahead inspections (the null kernel in flight owns d_max_tot)
-  JoinPlan* ahead = nullptr;            // the registered next join, consumed by the next join call
+  std::vector<JoinPlan>* ahead = nullptr;   // the registered later joins of the sequence, consumed by the next join call
+  bool ahead_closed = false;            // a join that cannot run ahead was offered: nothing behind it is registered either
   bool ahead_on = false;                // GCRE_AHEAD=1 turns gcre_join_ahead on.  Off by default: measured on configs[2], a pass takes
                                         // 31.5 ms with it and 31.4 without -- the next level's inspector and this level's permutation
                                         // kernel each fill the GPU, so running them side by side only trades the host-side gaps for
@@ -494,6 +496,20 @@ struct gcre_uids {
   mutable bool insp_valid = false;       // the join completed: every chunk entry describes it
   mutable bool insp_hinted = false;      // ... with the reduced operand standing (the hint was not broken)
   mutable uint64_t insp_res_ver = 0;     // version of the kept set's rows as that join left them
+  // A join on this index whose permutation kernels were LAUNCHED ahead (gcre_join_ahead chain): they write into the index's
+  // own maxima, the winners are the inspection cache's; the join call that comes for it only waits, copies and merges
+  struct Launched {
+    bool active = false;
+    InspKey key;
+    uint64_t res_ver = 0, mask_epoch = 0;
+    int win_k0 = 0, win_K = 0;
+    std::vector<Candidate> cands;
+    DevBuf<uint32_t> d_null;              // Kpad running maxima + one word: the launch's look-up counter
+    hipEvent_t done = nullptr;            // behind the last kernel of the launch (main stream)
+    gcre_profile prof{};                  // what the ahead inspection and the launch accumulated for this join
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_null, ev_stats;
+  };
+  mutable Launched launch;
   // optional hint (gcre_uids_set_reduced): paths0[idx] | paths1[loc] == paths0[idx] | red[red_index[loc]] for every
   // joined path; checked on the device for every join, ignored when it does not hold
   const gcre_pathset* red = nullptr;
@@ -1127,9 +1143,28 @@ void drop_ahead(gcre_ctx* c) {
   c->ahead = nullptr;
 }
 
+// a launch nobody came for (another window, other operands, the pass ended): wait for its kernels, forget it
+void drop_launch(const gcre_uids* u) {
+  if (u->launch.active && u->launch.done) (void)hipEventSynchronize(u->launch.done);
+  u->launch.active = false;
+  u->launch.cands.clear();
+  if (u->ctx) {
+    for (auto& pr : u->launch.ev_null) { u->ctx->ev_pool.push_back(pr.first); u->ctx->ev_pool.push_back(pr.second); }
+    for (auto& pr : u->launch.ev_stats) { u->ctx->ev_pool.push_back(pr.first); u->ctx->ev_pool.push_back(pr.second); }
+  }
+  u->launch.ev_null.clear();
+  u->launch.ev_stats.clear();
+  u->launch.prof = gcre_profile{};
+}
+
 void free_uids(gcre_uids* u) {
   if (!u) return;
-  if (u->ctx && u->ctx->ahead && u->ctx->ahead->u == u) drop_ahead(u->ctx);   // a registered next join names this index
+  if (u->ctx && u->ctx->ahead)   // a registered later join names this index
+    for (const JoinPlan& a : *u->ctx->ahead)
+      if (a.u == u) { drop_ahead(u->ctx); break; }
+  drop_launch(u);
+  u->launch.d_null.release();
+  if (u->launch.done) (void)hipEventDestroy(u->launch.done);
   if (u->ctx && u->ctx->stream) (void)hipStreamSynchronize(u->ctx->stream);
   if (u->ctx && u->ctx->insp_stream) (void)hipStreamSynchronize(u->ctx->insp_stream);
   if (u->ctx) {
@@ -1255,27 +1290,103 @@ int ensure_ranges(gcre_ctx* c, const gcre_uids& u) {
   return GCRE_OK;
 }
 
+// ---- merge: global heap starts with the {-inf,-1,-1,0,0} sentinel (join_base.cpp:192-194); the best
+// top_k of {sentinel} U candidates survive, reported in ascending order (format_result :140-151).
+// Ties: smaller joined-path ordinal wins (DESIGN.md "Ties").
+void merge_candidates(std::vector<Candidate>& cands, int top_k, gcre_result* out) {
+  std::sort(cands.begin(), cands.end(), [](const Candidate& a, const Candidate& b) {
+    if (a.score != b.score) return a.score > b.score;
+    return a.path < b.path;
+  });
+  size_t keepn = std::min(cands.size(), (size_t)top_k);
+  const bool with_sentinel = cands.size() < (size_t)top_k;
+  const size_t n_out = keepn + (with_sentinel ? 1 : 0);
+  out->n = (int32_t)n_out;
+  out->scores = (double*)std::calloc(std::max<size_t>(n_out, 1), sizeof(double));
+  out->src = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+  out->trg = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+  out->cases = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+  out->ctrls = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
+  size_t o = 0;
+  if (with_sentinel) {
+    out->scores[o] = -std::numeric_limits<double>::infinity();
+    out->src[o] = -1;
+    out->trg[o] = -1;
+    o++;
+  }
+  for (size_t i = keepn; i-- > 0;) {   // ascending: worst kept first
+    out->scores[o] = cands[i].score;
+    out->src[o] = cands[i].src;
+    out->trg[o] = cands[i].trg;
+    out->cases[o] = cands[i].cases;
+    out->ctrls[o] = cands[i].ctrls;
+    o++;
+  }
+}
+
+// The tail of a join whose kernels were launched ahead (run_join, kLaunch): wait for them, copy the maxima out of the join
+// index's own array, merge the winners its inspection cached.
+int finish_launched(gcre_ctx* c, const JoinPlan& jp, gcre_result* out) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  const gcre_uids& u = *jp.u;
+  gcre_uids::Launched& L = u.launch;
+  const int K = c->win_K;
+  const int Kpad = ((K + kPermTileMax - 1) / kPermTileMax) * kPermTileMax;
+  HIP_TRY(c, hipEventSynchronize(L.done));
+  L.active = false;
+  out->n_perm = K;
+  out->null_max = (float*)std::calloc((size_t)std::max(K, 1), sizeof(float));
+  uint32_t lookups = 0;
+  if (K > 0) {
+    // (on the inspection stream, idle by now: the main stream holds the later levels' kernels, which this join's caller
+    // need not wait for)
+    hipStream_t cs = c->insp_stream;
+    HIP_TRY(c, hipMemcpyAsync(out->null_max, L.d_null.p, (size_t)K * 4, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(c, hipMemcpyAsync(&lookups, L.d_null.p + Kpad, 4, hipMemcpyDeviceToHost, cs));
+    if (jp.d_null_out) HIP_TRY(c, hipMemcpyAsync(jp.d_null_out, L.d_null.p, (size_t)K * 4, hipMemcpyDeviceToDevice, cs));
+    HIP_TRY(c, hipStreamSynchronize(cs));
+  }
+  std::vector<Candidate> cands = std::move(L.cands);
+  L.cands.clear();
+  merge_candidates(cands, c->top_k, out);
+  c->prof = L.prof;
+  L.prof = gcre_profile{};
+  c->prof.null_kernel_ms = drain_events(c, L.ev_null);
+  c->prof.stats_kernel_ms = drain_events(c, L.ev_stats);
+  c->prof.ie_lookup_tiles += lookups;
+  c->prof.scores = c->prof.paths * (int64_t)K;
+  c->prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return GCRE_OK;
+}
+
 // inspect_only (gcre_join_ahead): the mask-independent half of the join -- expansion, inspector, kept rows, recipe, flags, top-k
 // winners -- on the inspection stream, into the join index's inspection cache; nothing of the permutation kernel's (no maxima,
 // no count planes, no results).  The join proper then replays it and starts at its null kernel.
-int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_only = false) {
+// kLaunch (the chain of gcre_join_ahead): the join's permutation kernels are launched -- on the main stream, into the join
+// index's own maxima, from the inspection that ran ahead -- and nothing is waited for; the call that comes for the join finds
+// it launched and only finishes it (wait, copy the maxima, merge the cached winners).
+enum JoinMode { kFull = 0, kInspect = 1, kLaunch = 2 };
+
+int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = kFull) {
+  const bool inspect_only = mode == kInspect, launch_only = mode == kLaunch;
   // the join sees the permutation window (all permutations unless gcre_set_perm_window narrowed it): K, the slice of
   // the transposed masks, of the masks (row stride stays the full Kpad) and of the maxima
   Geometry g = c->g;
   g.K = c->win_K;
   g.Kpad = ((g.K + kPermTileMax - 1) / kPermTileMax) * kPermTileMax;
   const int Kstride = c->g.Kpad;
-  uint32_t* const w_null = c->d_null ? c->d_null + c->win_k0 : nullptr;
+  uint32_t* w_null = c->d_null ? c->d_null + c->win_k0 : nullptr;
   const uint32_t* const w_masks = c->d_masks ? c->d_masks + c->win_k0 : nullptr;
   const uint32_t* const w_mt = c->d_mt ? c->d_mt + (size_t)(c->win_k0 / kSparseTile) * (size_t)(64 * g.Wp + 1) * 64 : nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   if (out) std::memset(out, 0, sizeof *out);
   // the registered next join (gcre_join_ahead) belongs to THIS call: taken here, inspected below once this join's own
   // kernels are in flight, dropped on every road out
-  std::unique_ptr<JoinPlan> ahead_plan;
-  if (!inspect_only) {
+  std::unique_ptr<std::vector<JoinPlan>> ahead_plan;
+  if (mode == kFull) {
     ahead_plan.reset(c->ahead);
     c->ahead = nullptr;
+    c->ahead_closed = false;
   }
   uint32_t* const flagblk = inspect_only ? c->d_max_tot_b : c->d_max_tot;
   if (!c->have_table) return fail(c, GCRE_ERR_ASSERT, "value table not set");
@@ -1313,6 +1424,17 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
     ikey.top_k = c->top_k;
     ikey.null_kernel = c->null_kernel;
     replay = u.insp_valid && u.insp_key == ikey && (!keep || jp.res->version == u.insp_res_ver);
+    if (launch_only && (!replay || jp.exchange || g.K <= 0)) return GCRE_OK;   // not launched: the join's own call runs it whole
+    if (mode == kFull && u.launch.active) {
+      // this join was launched ahead: if it is still the same join (operands, kept set, shard, table, window, masks) only its
+      // results are left to collect; otherwise its kernels are waited for and forgotten
+      const gcre_uids::Launched& L = u.launch;
+      if (replay && L.key == ikey && L.win_k0 == c->win_k0 && L.win_K == c->win_K && L.mask_epoch == c->mask_epoch &&
+          (!keep || jp.res->version == L.res_ver) && !jp.exchange)
+        return finish_launched(c, jp, out);
+      drop_launch(&u);
+    }
+    if (inspect_only) drop_launch(&u);          // (a stale launch of an earlier pass)
     if (inspect_only && replay) return GCRE_OK;   // already inspected (a later permutation window, kept inspections)
     if (!replay) {
       for (auto& ci : u.insp) {   // the buffers stay and serve the new chunks in turn
@@ -1322,8 +1444,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
       u.insp_key = ikey;
     }
     u.insp_valid = false;   // until this call completes
-  } else if (inspect_only) {
-    return GCRE_OK;   // no inspection cache, nothing to inspect ahead into
+  } else if (mode != kFull) {
+    return GCRE_OK;   // no inspection cache, nothing to inspect or launch ahead
   } else if (u.insp_valid || !u.insp.empty()) {
     for (auto& ci : u.insp) ci.release();
     u.insp.clear();
@@ -1356,19 +1478,49 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
 
   hipStream_t st = inspect_only ? c->insp_stream : c->stream;
   const int Kpad = g.Kpad;
+  // what an ahead inspection and an ahead launch cost is booked on the join they work for, not on the join they run beside
+  struct ProfSwap {
+    gcre_ctx* c;
+    gcre_uids::Launched* L;
+    ProfSwap(gcre_ctx* c_, gcre_uids::Launched* L_) : c(c_), L(L_) { swap(); }
+    ~ProfSwap() { swap(); }
+    void swap() {
+      if (!L) return;
+      std::swap(c->prof, L->prof);
+      std::swap(c->ev_null, L->ev_null);
+      std::swap(c->ev_stats, L->ev_stats);
+    }
+  } prof_swap(c, mode != kFull ? &u.launch : nullptr);
   if (inspect_only) {
     // behind the last inspector that ran on the main stream (its kept rows and recipe are this one's operands)
     HIP_TRY(c, hipStreamWaitEvent(st, c->ev_insp_main, 0));
   } else {
     // behind an inspection that ran ahead on its own stream (a no-op when there was none)
     HIP_TRY(c, hipStreamWaitEvent(st, c->ev_insp_done, 0));
-    if (Kpad > 0) HIP_TRY(c, hipMemsetAsync(w_null, 0, (size_t)Kpad * 4, st));
+    if (launch_only) {   // the launch's own maxima (+ its look-up counter): the context's belong to the join that is being finished
+      HIP_TRY(c, u.launch.d_null.reserve((size_t)Kpad + 64));
+      w_null = u.launch.d_null.p;
+      if (!u.launch.done && hipEventCreateWithFlags(&u.launch.done, hipEventDisableTiming) != hipSuccess)
+        return fail(c, GCRE_ERR_DEVICE, "hipEventCreate failed");
+      HIP_TRY(c, hipMemsetAsync(w_null, 0, ((size_t)Kpad + 1) * 4, st));
+    } else if (Kpad > 0) {
+      HIP_TRY(c, hipMemsetAsync(w_null, 0, (size_t)Kpad * 4, st));
+    }
   }
-  bool ahead_started = false;
-  auto run_ahead = [&]() -> int {
-    if (ahead_started || !ahead_plan) return GCRE_OK;
-    ahead_started = true;
-    return run_join(c, *ahead_plan, nullptr, true);
+  // The chain of gcre_join_ahead: once this join's own work is queued, every registered later join is inspected (on the
+  // inspection stream) and launched (on the main stream) in turn -- the big inspector of the last level then runs beside the
+  // small permutation kernels of the levels before it instead of after them
+  auto run_chain = [&]() -> int {
+    if (!ahead_plan) return GCRE_OK;
+    std::unique_ptr<std::vector<JoinPlan>> chain = std::move(ahead_plan);
+    for (const JoinPlan& a : *chain) {
+      if (int rc = run_join(c, a, nullptr, kInspect)) return rc;
+      if (int rc = run_join(c, a, nullptr, kLaunch)) return rc;
+      // a join that was not launched (its inspection did not validate: a broken hint) has not written what the joins
+      // behind it read: they run whole, in their own calls
+      if (!a.u->launch.active) break;
+    }
+    return GCRE_OK;
   };
 
   const NullConfig cfg = null_config(g.method, g.K);
@@ -1387,7 +1539,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
     return GCRE_OK;
   };
   std::vector<Candidate> cands;
-  if (!inspect_only) c->prof = gcre_profile{};   // (an ahead inspection's host times and replays count with the join it ran beside)
+  if (mode == kFull) c->prof = gcre_profile{};
   double select_ms = 0, select_wait_ms = 0;
   bool keep_planes_done = false;
   int64_t keep_planes_lo = 0, keep_planes_hi = 0;
@@ -1473,6 +1625,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
     uint32_t join_max_tot = 0, join_max_len = 0;
     bool ie_ran = false, ie_stat_pending = false, recipe_started = false, recipe_broken = false;
     auto collect_ie_stat = [&]() {
+      if (launch_only) ie_stat_pending = false;   // (its counter sits behind its maxima and is read when the join is finished)
       if (!ie_stat_pending) return;
       uint32_t v = 0;
       if (hipMemcpyAsync(&v, flagblk + 3, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
@@ -1770,9 +1923,11 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
             ci->in_recipe = use_ie && rcp != nullptr;
           }
         }
+        bool win_from_cache = false;
         if (hit && ci->win_valid && scored) {   // the chunk's top-k does not depend on the masks either
           win = ci->win;
           sel_done = true;
+          win_from_cache = true;
         }
         // the top-k selection only needs the keys the inspector just wrote: its digit passes run now, their state
         // comes back with the inspector's flags, its winners are collected before the null kernel starts
@@ -1935,7 +2090,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
           while (ia.waves_per_xcd > 4 && n * ie_tile_factor < (int64_t)8 * ia.waves_per_xcd * 32)
             ia.waves_per_xcd = std::max(4, (ia.waves_per_xcd / 2 / 4) * 4);
           c->prof.inspect_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
-          ia.stats = flagblk + 3;   // 4th word of the flag block: zeroed with it before k_stats ran
+          ia.stats = launch_only ? w_null + Kpad : flagblk + 3;   // 4th word of the flag block: zeroed with it before k_stats ran
           static uint64_t* d_timing = nullptr;   // diagnostics builds only (-DGCRE_IE_TIMING), GCRE_IE_TIMING=1
           const bool timing = std::getenv("GCRE_IE_TIMING") != nullptr;
           if (timing) {
@@ -2043,13 +2198,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
             if (int rc = queue_winners(s0, nsel, win, sel_on)) return rc;
             sel_done = true;
           }
-          // This join's kernels are in flight: the registered next join's inspector runs beside them (on its own stream,
-          // into its own buffers; the host waits for ITS flags while the GPU works on both).  Only behind the last chunk,
-          // and only when the selection scratch is free of this join's pending copies (own selection stream, or winners
-          // that came from the cache)
-          if (next >= sg.e && &sg == &segs.back() && (sel_on != st || !sel_begun))
-            if (int rc = run_ahead()) return rc;
-          if (timing) {
+          if (timing && !launch_only) {
             uint64_t tmv[8] = {0};
             HIP_TRY(c, hipMemcpyAsync(tmv, d_timing, 64, hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
@@ -2229,8 +2378,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
         }
         if (win.n > 0) {
           const auto tw0 = std::chrono::steady_clock::now();
-          if (sel_on != st) HIP_TRY(c, hipStreamSynchronize(sel_on));
-          HIP_TRY(c, hipStreamSynchronize(st));   // the null kernel of this chunk: its time is not the selection's
+          if (!win_from_cache) {   // (cached winners are host data: nothing to wait for)
+            if (sel_on != st) HIP_TRY(c, hipStreamSynchronize(sel_on));
+            HIP_TRY(c, hipStreamSynchronize(st));   // the null kernel of this chunk: its time is not the selection's
+          }
           select_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
           for (uint32_t i = 0; i < win.n; i++)
             cands.push_back(Candidate{key_to_score(win.key[i]), cb + s0 + (int64_t)win.sel[i], (int32_t)win.r0[i], (int32_t)win.r1[i],
@@ -2241,10 +2392,10 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
           ci->win_valid = true;
         }
         select_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count();
-        if (!inspect_only) c->prof.paths += s1 - s0;
+        if (!inspect_only) c->prof.paths += s1 - s0;   // (a launch books them on its own profile: prof_swap)
       }
     }
-    if (!inspect_only) collect_ie_stat();
+    if (mode == kFull) collect_ie_stat();
     if (rcp && want_ie && !recipe_broken) {
       // the recipe names its operands by id and row version: the set paths0 was, and the rows the join really added
       rcp->a_id = jp.p0->id;
@@ -2274,7 +2425,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
     HIP_TRY(c, hipEventRecord(c->ev_insp_done, st));
     return GCRE_OK;
   }
-  if (int rc = run_ahead()) return rc;   // (joins that took another road: no overlap, same result)
   if (keep_planes_done) {
     // the kept rows leave with their count planes: the next level's N0 (gcre_ie.hip)
     jp.res->planes_epoch = c->mask_epoch;
@@ -2289,6 +2439,20 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
   while (jp.exchange && exchanges_done < jp.exchanges)
     if (int rc = exchange_now()) return rc;
 
+  if (launch_only) {
+    // launched: the kernels are queued, nothing is waited for.  What the join's own call will need stays with the index
+    gcre_uids::Launched& L = u.launch;
+    HIP_TRY(c, hipEventRecord(L.done, st));
+    L.cands = std::move(cands);
+    L.key = ikey;
+    L.res_ver = keep ? jp.res->version : 0;
+    L.mask_epoch = c->mask_epoch;
+    L.win_k0 = c->win_k0;
+    L.win_K = c->win_K;
+    L.active = true;
+    return GCRE_OK;
+  }
+
   // ---- null maxima: first K entries, f32 (methods.h:101-102; format_result, join_base.cpp:144-146) ----
   out->n_perm = g.K;
   out->null_max = (float*)std::calloc((size_t)std::max(g.K, 1), sizeof(float));
@@ -2296,39 +2460,16 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, bool inspect_onl
     HIP_TRY(c, hipMemcpyAsync(out->null_max, w_null, (size_t)g.K * 4, hipMemcpyDeviceToHost, st));
     if (jp.d_null_out) HIP_TRY(c, hipMemcpyAsync(jp.d_null_out, w_null, (size_t)g.K * 4, hipMemcpyDeviceToDevice, st));
   }
-  HIP_TRY(c, hipStreamSynchronize(st));
+  if (ahead_plan) {
+    // this join's copies are queued: the chain goes behind them, and only they are waited for
+    HIP_TRY(c, hipEventRecord(c->ev_tail, st));
+    if (int rc = run_chain()) return rc;
+    HIP_TRY(c, hipEventSynchronize(c->ev_tail));
+  } else {
+    HIP_TRY(c, hipStreamSynchronize(st));
+  }
 
-  // ---- merge: global heap starts with the {-inf,-1,-1,0,0} sentinel (join_base.cpp:192-194); the best
-  // top_k of {sentinel} U candidates survive, reported in ascending order (format_result :140-151).
-  // Ties: smaller joined-path ordinal wins (DESIGN.md "Ties").
-  std::sort(cands.begin(), cands.end(), [](const Candidate& a, const Candidate& b) {
-    if (a.score != b.score) return a.score > b.score;
-    return a.path < b.path;
-  });
-  size_t keepn = std::min(cands.size(), (size_t)c->top_k);
-  const bool with_sentinel = cands.size() < (size_t)c->top_k;
-  const size_t n_out = keepn + (with_sentinel ? 1 : 0);
-  out->n = (int32_t)n_out;
-  out->scores = (double*)std::calloc(std::max<size_t>(n_out, 1), sizeof(double));
-  out->src = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
-  out->trg = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
-  out->cases = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
-  out->ctrls = (int32_t*)std::calloc(std::max<size_t>(n_out, 1), sizeof(int32_t));
-  size_t o = 0;
-  if (with_sentinel) {
-    out->scores[o] = -std::numeric_limits<double>::infinity();
-    out->src[o] = -1;
-    out->trg[o] = -1;
-    o++;
-  }
-  for (size_t i = keepn; i-- > 0;) {   // ascending: worst kept first
-    out->scores[o] = cands[i].score;
-    out->src[o] = cands[i].src;
-    out->trg[o] = cands[i].trg;
-    out->cases[o] = cands[i].cases;
-    out->ctrls[o] = cands[i].ctrls;
-    o++;
-  }
+  merge_candidates(cands, c->top_k, out);
 
   c->prof.null_kernel_ms = drain_events(c, c->ev_null);
   c->prof.stats_kernel_ms = drain_events(c, c->ev_stats);
@@ -2416,6 +2557,7 @@ gcre_ctx* gcre_create(int method, int n_cases, int n_ctrls, int iterations, int 
   ok = ok && hipStreamCreateWithFlags(&c->insp_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_insp_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_insp_main, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) == hipSuccess;
   if (const char* e = std::getenv("GCRE_AHEAD")) c->ahead_on = std::atoi(e) != 0;
   ok = ok && hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_sel_done, hipEventDisableTiming) == hipSuccess;
@@ -2484,6 +2626,7 @@ void gcre_destroy(gcre_ctx* c) {
   if (c->insp_stream) (void)hipStreamDestroy(c->insp_stream);
   if (c->ev_insp_done) (void)hipEventDestroy(c->ev_insp_done);
   if (c->ev_insp_main) (void)hipEventDestroy(c->ev_insp_main);
+  if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
   if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
   if (c->ev_sel_done) (void)hipEventDestroy(c->ev_sel_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2563,7 +2706,9 @@ int gcre_drop_inspections(gcre_ctx* c, int release_memory) {
   if (!c) return GCRE_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (release_memory && c->stream) (void)hipStreamSynchronize(c->stream);
+  drop_ahead(c);
   for (gcre_uids* u : c->live_uids) {
+    drop_launch(u);
     u->insp_valid = false;
     if (release_memory) {
       for (auto& ci : u->insp) ci.release();
@@ -2862,7 +3007,10 @@ void gcre_pathset_free(gcre_pathset* ps) {
     (void)hipSetDevice(ps->ctx->device);
     if (ps->ctx->stream) (void)hipStreamSynchronize(ps->ctx->stream);
     if (ps->ctx->insp_stream) (void)hipStreamSynchronize(ps->ctx->insp_stream);
-    if (ps->ctx->ahead && (ps->ctx->ahead->p0 == ps || ps->ctx->ahead->p1 == ps || ps->ctx->ahead->res == ps)) drop_ahead(ps->ctx);
+    if (ps->ctx->ahead)
+      for (const JoinPlan& a : *ps->ctx->ahead)
+        if (a.p0 == ps || a.p1 == ps || a.res == ps) { drop_ahead(ps->ctx); break; }
+    for (gcre_uids* lu : ps->ctx->live_uids) drop_launch(lu);   // (a launched join may read or write this set)
   }
   if (ps->d_rows) (void)hipFree(ps->d_rows);
   drop_lists(ps);   // lists, and the plane buffer goes to the context's pool
@@ -2953,16 +3101,20 @@ int gcre_join_uids(gcre_ctx* c, const gcre_uids* uids, const gcre_pathset* paths
 int gcre_join_ahead(gcre_ctx* c, const gcre_uids* uids, const gcre_pathset* paths0, const gcre_pathset* paths1,
                     gcre_pathset* res, const gcre_join_opts* opts) {
   if (!c) return GCRE_ERR_ARG;
-  drop_ahead(c);
-  if (!uids) return GCRE_OK;   // (cancels a registration)
-  if (!c->ahead_on || !c->insp_cache) return GCRE_OK;   // nothing to inspect ahead into: the next join simply runs whole
+  if (!uids) { drop_ahead(c); c->ahead_closed = false; return GCRE_OK; }   // (cancels the registrations)
+  if (!c->ahead_on || !c->insp_cache || c->ahead_closed) return GCRE_OK;   // nothing to inspect ahead into: the joins simply run whole
   if (uids->ctx != c || !paths0 || !paths1 || paths0->ctx != c || paths1->ctx != c || (res && res->ctx != c))
     return fail(c, GCRE_ERR_ARG, "uids / path set do not belong to this context");
-  c->ahead = new JoinPlan{uids, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0,
-                          opts ? opts->shard_end : 0, nullptr};
-  c->ahead->take(opts);
-  c->ahead->exchanges = 0;       // an inspection exchanges nothing
-  c->ahead->exchange = nullptr;
+  if (opts && opts->exchange && opts->exchanges > 0) {
+    // a join that exchanges thresholds with other devices runs whole, in its own call -- and so does everything behind it in
+    // the sequence (it reads what this one writes)
+    c->ahead_closed = true;
+    return GCRE_OK;
+  }
+  if (!c->ahead) c->ahead = new std::vector<JoinPlan>();
+  JoinPlan a{uids, paths0, paths1, res, opts && opts->sharded, opts ? opts->shard_begin : 0, opts ? opts->shard_end : 0, nullptr};
+  a.take(opts);
+  c->ahead->push_back(a);
   return GCRE_OK;
 }
 
