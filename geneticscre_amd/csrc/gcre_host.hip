@@ -1424,7 +1424,8 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
     ikey.top_k = c->top_k;
     ikey.null_kernel = c->null_kernel;
     replay = u.insp_valid && u.insp_key == ikey && (!keep || jp.res->version == u.insp_res_ver);
-    if (launch_only && (!replay || jp.exchange || g.K <= 0)) return GCRE_OK;   // not launched: the join's own call runs it whole
+    // not launched: the join's own call runs it whole
+    if (launch_only && (!replay || jp.exchange || g.K <= 0)) return GCRE_OK;
     if (mode == kFull && u.launch.active) {
       // this join was launched ahead: if it is still the same join (operands, kept set, shard, table, window, masks) only its
       // results are left to collect; otherwise its kernels are waited for and forgotten
@@ -1513,7 +1514,24 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
   auto run_chain = [&]() -> int {
     if (!ahead_plan) return GCRE_OK;
     std::unique_ptr<std::vector<JoinPlan>> chain = std::move(ahead_plan);
+    int budget = 1 << 30;   // GCRE_AHEAD_MAX (diagnostics): how many of the registered joins run ahead
+    if (const char* e = std::getenv("GCRE_AHEAD_MAX")) budget = std::atoi(e);
     for (const JoinPlan& a : *chain) {
+      if (budget-- <= 0) break;
+      // Joins of several chunks do not run ahead (nor does anything behind them).  OPEN: with a level-3 join of two chunks
+      // inspected ahead -- kept in full, scored on a shard that spans both chunks -- the level-4 join behind it (pivot-group
+      // shards) came out with 14 of 2,300 maxima too high on that one rank of five (fuzz case 6100095 of the sharded-plan test,
+      // GCRE_AHEAD=1 GCRE_CHUNK_PATHS=700 GCRE_PIVOT_SHARDS=1; tools/diag/fuzz_case.py reproduces it when this check is
+      // removed).  The cause was not found in the time there was; a chunk holds 2^25 joined paths, so outside tests only
+      // joins that large are affected, and they run whole as they always did.
+      {
+        const int64_t tile = null_config(c->g.method, c->win_K).path_tile;
+        if (a.u->total > std::max<int64_t>(tile, (c->chunk_paths / tile) * tile)) break;
+      }
+      if (std::getenv("GCRE_AHEAD_INSPECT_ONLY")) {   // (diagnostics: inspections ahead, no launches)
+        if (int rc = run_join(c, a, nullptr, kInspect)) return rc;
+        continue;
+      }
       if (int rc = run_join(c, a, nullptr, kInspect)) return rc;
       if (int rc = run_join(c, a, nullptr, kLaunch)) return rc;
       // a join that was not launched (its inspection did not validate: a broken hint) has not written what the joins
@@ -2246,6 +2264,15 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
         }
         if (!scored) continue;
 
+        if (g.K > 0 && use_sparse && inspect_only && ci) {
+          // the delta-streaming road sizes its counters from the inspector's flag block: an ahead inspection reads it now and
+          // leaves it with the chunk (the launch that replays the chunk finds the block cleared)
+          uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          HIP_TRY(c, hipMemcpyAsync(flags, flagblk, 32, hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipStreamSynchronize(st));
+          std::memcpy(ci->flags, flags, sizeof flags);
+          ci->flags_valid = true;
+        }
         if (g.K > 0 && use_sparse && !inspect_only) do {
           // inspector (once per chunk, shared by all permutation tiles): per joined path the bits paths1 adds
           // on top of paths0 -> offsets by a device scan of the counts k_stats left, entries by k_delta_fill
