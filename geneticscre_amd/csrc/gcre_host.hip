@@ -1397,6 +1397,61 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
   const gcre_uids& u = *jp.u;
 
   // ---- the checks of JoinExec::join, join_base.cpp:196-200 ----
+
+  // ---- the checks of JoinExec::join, join_base.cpp:196-200 ----
+  if (mode == kFull && std::getenv("GCRE_DUMP_P0")) {   // (diagnostics: what this join finds in paths0 and its recipe)
+    (void)hipDeviceSynchronize();
+    auto fnv = [&](const void* d, size_t bytes) -> unsigned long long {
+      std::vector<unsigned char> h(bytes);
+      if (bytes && hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0ull;
+      unsigned long long x = 1469598103934665603ull;
+      for (unsigned char b : h) { x ^= b; x *= 1099511628211ull; }
+      return x;
+    };
+    const gcre_pathset* p0 = jp.p0;
+    const size_t nr = (size_t)p0->nrows, M = (size_t)c->g.method;
+    std::fprintf(stderr, "[dump dev %d] p0 id %llu rows %zu: rows %016llx", c->device, (unsigned long long)p0->id, nr,
+                 fnv(p0->d_rows, nr * M * (size_t)c->g.S * 8));
+    if (p0->rec && p0->rec->valid) {
+      const gcre_recipe* r = p0->rec;
+      std::fprintf(stderr, " rec row0 %016llx rowz %016llx linfo %016llx lover %016llx tot %016llx slot %016llx max_len %u", fnv(r->row0.p, nr * 4),
+                   fnv(r->rowz.p, nr * 4), fnv(r->linfo.p, nr * M * 4), fnv(r->lover.p, nr * M * 4), fnv(r->tot.p, nr * M * 4),
+                   fnv(r->slot.p, nr * M * 32), r->max_len);
+    }
+    if (p0->rec && p0->rec->valid) {   // the lists as the kernels resolve them: slot entries, then the overflow part
+      const gcre_recipe* r = p0->rec;
+      const size_t nl = nr * M;
+      std::vector<uint32_t> linfo(nl), lover(nl), slot(nl * 8);
+      (void)hipMemcpy(linfo.data(), r->linfo.p, nl * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(lover.data(), r->lover.p, nl * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(slot.data(), r->slot.p, nl * 32, hipMemcpyDeviceToHost);
+      size_t need = 0;
+      for (size_t d = 0; d < nl; d++) {
+        const uint32_t len8 = linfo[d] & 0x0ffffff8u;
+        if (len8 > 8) need = std::max(need, (size_t)lover[d] + (len8 - 8));
+      }
+      std::vector<uint32_t> over(std::min(need, r->over.cap));
+      if (!over.empty()) (void)hipMemcpy(over.data(), r->over.p, over.size() * 4, hipMemcpyDeviceToHost);
+      unsigned long long x = 1469598103934665603ull;
+      size_t longl = 0, beyond = 0;
+      for (size_t d = 0; d < nl; d++) {
+        const uint32_t len8 = linfo[d] & 0x0ffffff8u;
+        std::vector<uint32_t> e(slot.begin() + (long)d * 8, slot.begin() + (long)d * 8 + 8);
+        if (len8 > 8) {
+          longl++;
+          for (uint32_t k = 0; k < len8 - 8; k++) {
+            const size_t at = (size_t)lover[d] + k;
+            if (at < over.size()) e.push_back(over[at]); else beyond++;
+          }
+        }
+        std::sort(e.begin(), e.end());
+        for (uint32_t v : e) { x ^= v; x *= 1099511628211ull; }
+      }
+      std::fprintf(stderr, " lists %016llx (long %zu, beyond %zu, over used %zu of cap %zu)", x, longl, beyond, need, r->over.cap);
+    }
+    std::fprintf(stderr, " max_bits %u known %d planes_valid %d [%lld,%lld) groups %d\n", p0->max_bits, (int)p0->max_known, (int)p0->planes_valid,
+                 (long long)p0->planes_lo, (long long)p0->planes_hi, p0->plane_groups);
+  }
   if (u.n_uids != jp.p0->nrows) return fail(c, GCRE_ERR_ASSERT, "assertion: uids.size() != paths0.size");
   if (u.max_loc >= jp.p1->nrows) return fail(c, GCRE_ERR_RANGE, "assertion: uid location out of range");
   const int64_t P = u.total;
@@ -1518,16 +1573,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
     if (const char* e = std::getenv("GCRE_AHEAD_MAX")) budget = std::atoi(e);
     for (const JoinPlan& a : *chain) {
       if (budget-- <= 0) break;
-      // Joins of several chunks do not run ahead (nor does anything behind them).  OPEN: with a level-3 join of two chunks
-      // inspected ahead -- kept in full, scored on a shard that spans both chunks -- the level-4 join behind it (pivot-group
-      // shards) came out with 14 of 2,300 maxima too high on that one rank of five (fuzz case 6100095 of the sharded-plan test,
-      // GCRE_AHEAD=1 GCRE_CHUNK_PATHS=700 GCRE_PIVOT_SHARDS=1; tools/diag/fuzz_case.py reproduces it when this check is
-      // removed).  The cause was not found in the time there was; a chunk holds 2^25 joined paths, so outside tests only
-      // joins that large are affected, and they run whole as they always did.
-      {
-        const int64_t tile = null_config(c->g.method, c->win_K).path_tile;
-        if (a.u->total > std::max<int64_t>(tile, (c->chunk_paths / tile) * tile)) break;
-      }
       if (std::getenv("GCRE_AHEAD_INSPECT_ONLY")) {   // (diagnostics: inspections ahead, no launches)
         if (int rc = run_join(c, a, nullptr, kInspect)) return rc;
         continue;
@@ -1642,6 +1687,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
     gcre_recipe* rcp = nullptr;   // the recipe this join leaves with the rows it keeps (method 1)
     uint32_t join_max_tot = 0, join_max_len = 0;
     bool ie_ran = false, ie_stat_pending = false, recipe_started = false, recipe_broken = false;
+    uint32_t over_next = 0;   // entries of the kept set's overflow area (gcre_recipe::over) handed out to this join's chunks so far
     auto collect_ie_stat = [&]() {
       if (launch_only) ie_stat_pending = false;   // (its counter sits behind its maxima and is read when the join is finished)
       if (!ie_stat_pending) return;
@@ -1885,6 +1931,9 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
           collect_ie_stat();
           // flags of this chunk; the long-list counter (word 4) runs on across the chunks of a join that keeps a recipe
           HIP_TRY(c, hipMemsetAsync(flagblk, 0, (rcp && recipe_started) ? 16 : 24, st));   // words 6, 7: the join's
+          // ... and word 4, the entries reserved so far in the recipe's overflow area, is the JOIN's, not the flag block's: a
+          // chunk replayed from the inspection cache never touched this block, and an ahead inspection ran on the other one
+          if (rcp) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(flagblk + 4), (int)over_next, 1, st));
           recipe_started = recipe_started || rcp != nullptr;
           sa.max_tot = flagblk;
           HIP_TRY(c, hold(c->d_dcnt, (size_t)n * g.method));
@@ -1983,6 +2032,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
             break;
           }
           const uint64_t n_list = (uint64_t)nl * 8 + flags[4];
+          if (rcp) over_next = std::max(over_next, flags[4]);
           const uint32_t max_tot = flags[0];
           join_max_tot = std::max(join_max_tot, max_tot);
           join_max_len = std::max(join_max_len, flags[5]);

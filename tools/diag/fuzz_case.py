@@ -9,6 +9,7 @@ from test_gpu_exchange import run_ranks
 case = int(sys.argv[1]); world = int(sys.argv[2])
 cfg, env = f.draw(case)
 env["GCRE_WINDOW_TILES"] = ""
+# (the sharded-plan test adds GCRE_EXCHANGE_UNIT = [5, 50, 2000][case % 3] and GCRE_PIVOT_SHARDS = case % 2 to the draw: pass them here)
 for kv in sys.argv[3:]:
     k, v = kv.split("="); env[k] = v
 for k, v in env.items():
