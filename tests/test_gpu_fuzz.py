@@ -147,6 +147,26 @@ def test_random_sharded_plan_matches_oracle(case, monkeypatch):
     check_merged(parts, want, p, min(cfg["length"], 4))
 
 
+def test_launch_ahead_keeps_the_recipe_lists_when_a_chunk_is_split_again(monkeypatch):
+    """Fuzz case 6100095 of the sharded-plan test under GCRE_AHEAD=1, kept as a regression: rank 3 of 5 inspects its two-chunk
+    level-3 join ahead, the launch pass splits the second chunk again at the shard's end, and the re-inspected pieces must
+    not reserve their long lists over those of the first chunk (the recipe's overflow counter belongs to the join)."""
+    cfg, env = draw(6100095)
+    env.update({"GCRE_WINDOW_TILES": "", "GCRE_EXCHANGE_UNIT": "2000", "GCRE_PIVOT_SHARDS": "1", "GCRE_AHEAD": "1"})
+    for k, v in env.items():
+        if v:
+            monkeypatch.setenv(k, v)
+        else:
+            monkeypatch.delenv(k, raising=False)
+    K = max(cfg["perms"], 1)
+    p = make_problem(cfg["genes"], cfg["edges"], cfg["n_cases"], cfg["n_ctrls"], K, min(cfg["length"], 4),
+                     method=cfg["method"], top_k=cfg["top_k"], seed=cfg["seed"], threshold=cfg["threshold"],
+                     table=value_table(cfg["table"], cfg["n_cases"], cfg["n_ctrls"], cfg["seed"]))
+    want = oracle.process_paths(p, order="canonical")
+    parts, _, _ = run_ranks(p, 5, K)
+    check_merged(parts, want, p, min(cfg["length"], 4))
+
+
 @pytest.mark.parametrize("case", range(max(1, N_CASES // 4)))
 def test_random_resident_plan_with_kept_inspections(case, monkeypatch):
     """ResidentPlan over the same draw: a pass, a pass that keeps its inspections, a pass that replays them under another
