@@ -440,6 +440,7 @@ struct gcre_pathset {
   mutable std::vector<uint64_t> h_loff;   // host copy of the offsets (sizes the work of a sparse launch)
   mutable uint32_t max_bits = 0;          // longest list (entries incl. padding): bounds the carriers of any row
   mutable bool max_known = false;
+  mutable int one_sided = -1;             // method 2: every row has an empty half (-1: not looked at; from h_loff)
   // count planes for the inclusion-exclusion kernel: [tile][row*M+h][groups][64][4] dwords, valid for one mask epoch
   mutable uint32_t* d_planes = nullptr;
   mutable int plane_groups = 0;
@@ -659,6 +660,7 @@ void drop_lists(const gcre_pathset* ps) {
   ps->h_loff.clear();
   ps->max_bits = 0;
   ps->max_known = false;
+  ps->one_sided = -1;
   drop_planes(ps);
 }
 
@@ -700,6 +702,19 @@ int ensure_lists(gcre_ctx* c, const gcre_pathset* ps) {
   ps->max_bits = longest;
   ps->max_known = true;
   return GCRE_OK;
+}
+
+// method 2: does every row of the set have an empty half?  (genes: a row's carriers sit in one half.)  From the host copy of
+// the list offsets, once per set of lists.
+bool one_sided(const gcre_pathset* ps) {
+  if (!ps->d_loff || ps->h_loff.size() != (size_t)ps->nrows * 2 + 1) return false;
+  if (ps->one_sided < 0) {
+    int yes = 1;
+    for (int64_t r = 0; r < ps->nrows && yes; r++)
+      if (ps->h_loff[(size_t)2 * r + 1] > ps->h_loff[(size_t)2 * r] && ps->h_loff[(size_t)2 * r + 2] > ps->h_loff[(size_t)2 * r + 1]) yes = 0;
+    ps->one_sided = yes;
+  }
+  return ps->one_sided == 1;
 }
 
 // largest number of carriers a row of the set can have (from its lists, or from the join that produced it)
@@ -1974,6 +1989,7 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
           }
           sa.ov_count = flagblk + 4;
           sa.zoff = (uint32_t)(64 * g.Wp) << 8;
+          if (g.method == 2 && one_sided(red)) sa.lz_off = red->d_loff;   // one round per path instead of one per half
           if (!hit) HIP_TRY(c, launch_stats_ie(sa, g.method, st));
           // a kept row's carrier total bounds every count of it: the next level loads only the plane groups that can be non-zero
           if (rcp && !hit) HIP_TRY(c, hipMemcpyAsync(rcp->tot.p + (size_t)cb * g.method, c->d_tot.p, (size_t)n * g.method * 4, hipMemcpyDeviceToDevice, st));

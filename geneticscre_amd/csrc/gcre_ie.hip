@@ -1991,6 +1991,287 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? G
   if (my_max_len > 8u) atomicMax(a.max_tot + 5, my_max_len);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The signed method's inspector when every reduced row has an EMPTY half (genes: a gene's carriers sit in one half, the
+// other half of its row is zero -- every join below level 5).  Then only one half of a joined path differs from its paths0
+// row: k_stats_ie2s spends a round of sixteen lanes on each half of every path, this kernel one round per PATH --
+// the half that changes (side of the reduced row, flipped when the relation's sign says so) -- and takes the other half's
+// carriers from the paths0 row, counted once per uid when a group of lanes moves on to it (both halves of that row stay in
+// registers: consecutive paths of a uid change either half).  A wave owns 64 consecutive paths.  Same outputs as
+// k_stats_ie2s except the (unused) overflow offset of an empty list.  a.lz_off: the CSR offsets of the reduced rows' bit
+// lists (two lists per row): list 2 r + 1 empty <=> the (-) half of row r is.
+// ------------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3 : 2))) void k_stats_ie2h(const StatsArgs a) {
+  typedef u64 __attribute__((ext_vector_type(2))) u64x2;
+  constexpr u32 kNoRange = 0xffffffffu;
+  constexpr u32 kOverChunk = 2048;
+  __shared__ u32 slot_lds[4][64 * 8];   // the 64 paths' list slots (of the half that changes)
+  __shared__ u32 out_lds[4][7][64];     // per path: carriers (+), (-), among the cases (+), (-), linfo, lover, the half that changes
+  __shared__ u32 pair_lds[4][4][3][32 * NL];
+  __shared__ u32 meta_lds[4][5][64];    // per path: paths0 row, reduced row | flip, range, swap of paths1, side of the reduced row
+  __shared__ u64 cm_lds[32 * NL];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sl = lane & 15, grp = lane >> 4;
+  const u32 gsh = (u32)grp * 16u, ltm = (1u << sl) - 1u;
+  u32 (*pairs)[32 * NL] = pair_lds[wv][grp];
+  u32 (*meta)[64] = meta_lds[wv];
+  const i64 wave = (i64)blockIdx.x * 4 + wv;
+  const i64 nwaves = (i64)gridDim.x * 4;
+  const int Wp = a.Wp;
+  u32* slots = slot_lds[wv];
+  u32 (*outs)[64] = out_lds[wv];
+  u32 my_max_tot = 0, my_modes = 0, my_max_len = 0;
+  bool my_bad = false;
+  u32 chunk_at = 0u, chunk_left = 0u;
+  for (int k = (int)threadIdx.x; k < 32 * NL; k += 256) cm_lds[k] = k < Wp ? a.case_mask[k] : 0;
+  __syncthreads();
+  // an empty list as the inspector writes it: no entries, eight of padding (the bias rule of the signed method: delta list)
+  const u32 empty_mode = a.ie_rule ? 1u : 0u;   // (overlap 0, delta 0: the slot rule says overlap list, the bias rule delta list)
+  const u32 empty_linfo = 8u | empty_mode | (8u << 28);
+  const i64 nblocks = (a.count + 63) / 64;
+  for (i64 blk = wave; blk < nblocks; blk += nwaves) {
+    const i64 base = blk * 64;
+    {
+      // ---- the 64 paths' row numbers, one coalesced load per array (lane t <-> path base + t) ----
+      const i64 iq = base + lane < a.count ? base + lane : a.count - 1;
+      const u32 r0v = a.row0[iq];
+      const u32 r1v = a.row1[iq];
+      const u32 zraw = a.zindex ? (u32)a.zindex[r1v & 0x7fffffffu] : (r1v & 0x7fffffffu);
+      const u32 zflip = (r1v ^ (a.zindex ? zraw : 0u)) & 0x80000000u;
+      const u32 zrow = zraw & 0x7fffffffu;
+      u32 rngv = kNoRange;   // the uid's row of the excess table, for the first path of a uid in this launch only
+      if (a.excess && (iq == 0 || a.row0[iq - 1] != r0v)) rngv = (u32)a.range_of[r0v];
+      const u32 side = a.lz_off[2 * (size_t)zrow + 2] > a.lz_off[2 * (size_t)zrow + 1] ? 1u : 0u;   // the row's (-) half has carriers
+      meta[0][lane] = r0v;
+      meta[1][lane] = zrow | zflip;
+      meta[2][lane] = rngv;
+      meta[3][lane] = r1v >> 31;
+      meta[4][lane] = side;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      const u32x4 pad = {a.zoff, a.zoff, a.zoff, a.zoff};
+      ((u32x4*)slots)[lane * 2] = pad;
+      ((u32x4*)slots)[lane * 2 + 1] = pad;
+    }
+    u64 xw[2][NL][2], zw[NL][2];
+#pragma unroll
+    for (int it = 0; it < NL; it++) xw[0][it][0] = xw[0][it][1] = xw[1][it][0] = xw[1][it][1] = zw[it][0] = zw[it][1] = 0ull;
+    u32 n_rzf = 0u, n_rng = kNoRange, n_r0 = 0xffffffffu, n_swap = 0u, n_hc = 0u;
+    bool n_newx = false;
+    auto fetch_rows = [&](int itn) {
+      const int pln = itn * 4 + grp;
+      const u32 r0n = meta[0][pln];
+      n_rzf = meta[1][pln];
+      n_rng = meta[2][pln];
+      n_swap = meta[3][pln];
+      const u32 side = meta[4][pln];
+      n_hc = (n_rzf >> 31) ? 1u - side : side;   // the half of the joined path the reduced row's carriers land in
+      n_newx = r0n != n_r0;
+      n_r0 = r0n;
+      const u64* xn = a.p0 + (size_t)r0n * a.S;
+      const u64* zn = a.pz + (size_t)(n_rzf & 0x7fffffffu) * a.S + (size_t)side * Wp;
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+        const int k = it * 32 + 2 * sl;
+        if (k < Wp) {
+          if (n_newx) {
+            const u64x2 v0 = *(const u64x2*)(xn + k);
+            const u64x2 v1 = *(const u64x2*)(xn + Wp + k);
+            xw[0][it][0] = v0.x; xw[0][it][1] = v0.y;
+            xw[1][it][0] = v1.x; xw[1][it][1] = v1.y;
+          }
+          const u64x2 v = *(const u64x2*)(zn + k);
+          zw[it][0] = v.x; zw[it][1] = v.y;
+        }
+      }
+    };
+    fetch_rows(0);
+    u32 tx0 = 0u, tx1 = 0u;   // carriers | carriers among the cases << 16 of the paths0 row's halves
+    for (int it4 = 0; it4 < 16; it4++) {
+      const int pl = it4 * 4 + grp;                 // the group's path inside the block
+      const bool active = base + pl < a.count;
+      if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+      const u32 rng = n_rng, swap = n_swap, hc = n_hc;
+      const bool newx = n_newx;
+      // ---- a new paths0 row: the carriers of both its halves; (first path of a uid) the check of the hint, both halves ----
+      if (__builtin_amdgcn_ballot_w64(newx) != 0ull) {
+        u32 c0 = 0u, c1 = 0u;
+        u64 stray = 0;
+        // the excess row is in paths1's orientation: its half (swap ? 1 - h : h) lands in half h
+        const u64* uu = (newx && rng != kNoRange) ? a.excess + (size_t)rng * a.S : nullptr;
+#pragma unroll
+        for (int it = 0; it < NL; it++) {
+          const int k = it * 32 + 2 * sl;
+          const u64x2 cmv = *(const u64x2*)(cm_lds + k);
+          c0 += ((u32)__popcll(xw[0][it][0]) + (u32)__popcll(xw[0][it][1])) |
+                (((u32)__popcll(xw[0][it][0] & cmv.x) + (u32)__popcll(xw[0][it][1] & cmv.y)) << 16);
+          c1 += ((u32)__popcll(xw[1][it][0]) + (u32)__popcll(xw[1][it][1])) |
+                (((u32)__popcll(xw[1][it][0] & cmv.x) + (u32)__popcll(xw[1][it][1] & cmv.y)) << 16);
+          if (uu && k < Wp) {
+            const u64x2 u0 = *(const u64x2*)(uu + (size_t)(swap ? 1 : 0) * Wp + k);   // lands in half 0
+            const u64x2 u1 = *(const u64x2*)(uu + (size_t)(swap ? 0 : 1) * Wp + k);   // lands in half 1
+            stray |= (u0.x & ~xw[0][it][0]) | (u0.y & ~xw[0][it][1]) | (u1.x & ~xw[1][it][0]) | (u1.y & ~xw[1][it][1]);
+          }
+        }
+        if (stray) my_bad = true;
+        const u32 t0 = row_total(c0, lane), t1 = row_total(c1, lane);
+        if (newx) { tx0 = t0; tx1 = t1; }
+      }
+      u64* out = (a.res && active) ? a.res + (size_t)(a.first + base + pl) * a.S : nullptr;
+      // ---- the half that changes ----
+      u32 cc = 0u, dv = 0u;
+      u64 xk_[NL][2];
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+        const int k = it * 32 + 2 * sl;
+        const u64x2 cmv = *(const u64x2*)(cm_lds + k);
+        const u64 cme[2] = {cmv.x, cmv.y};
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const u64 xk = hc ? xw[1][it][e] : xw[0][it][e], zk = zw[it][e];
+          xk_[it][e] = xk;
+          const u64 j = xk | zk;
+          cc += (u32)__popcll(j & cme[e]) | ((u32)__popcll(j) << 16);
+          dv += (u32)__popcll(zk & ~xk) | ((u32)__popcll(zk) << 16);
+        }
+        if (out && k < Wp) {   // the kept row: the changed half joined, the other as it was
+          const u64x2 jc = u64x2{xk_[it][0] | zw[it][0], xk_[it][1] | zw[it][1]};
+          const u64x2 ju = hc ? u64x2{xw[0][it][0], xw[0][it][1]} : u64x2{xw[1][it][0], xw[1][it][1]};
+          *(u64x2*)(out + (size_t)hc * Wp + k) = jc;
+          *(u64x2*)(out + (size_t)(1u - hc) * Wp + k) = ju;
+        }
+      }
+      const u32 c = row_total(cc, lane), d = row_total(dv, lane);
+      const u32 inc = c & 0xffffu, tot = c >> 16;
+      const u32 dl = d & 0xffffu, ov = (d >> 16) - dl;
+      const u32 mode = a.ie_rule ? ((ov <= 8u || ov < dl) ? 1u : 0u) : ((a.ie_bias >= 0 && ov + (u32)a.ie_bias < dl) ? 1u : 0u);
+      const u32 len = mode ? ov : dl;
+      const u32 len8 = max(8u, (len + 7u) & ~7u);
+      u32 npair = 0u;
+#pragma unroll
+      for (int it = 0; it < NL; it++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const u64 w = mode ? (zw[it][e] & xk_[it][e]) : (zw[it][e] & ~xk_[it][e]);
+          const bool nz = active && w != 0;
+          const u64 bal = __builtin_amdgcn_ballot_w64(nz);
+          if (bal == 0ull) continue;
+          const u32 m = (u32)(bal >> gsh) & 0xffffu;
+          const u32 at = npair + (u32)__builtin_popcount(m & ltm);
+          if (nz) {
+            pairs[0][at] = (u32)w;
+            pairs[1][at] = (u32)(w >> 32);
+            pairs[2][at] = (u32)(it * 32 + 2 * sl + e);
+          }
+          npair += (u32)__builtin_popcount(m);
+        }
+      }
+      // the other half's carriers: the paths0 row's
+      const u32 tu = hc ? tx0 : tx1;
+      const u32 tot_u = tu & 0xffffu, inc_u = tu >> 16;
+      fetch_rows(it4 < 15 ? it4 + 1 : 15);   // (changes the NEXT iteration's words and row numbers only)
+      if (active && sl == 0) {
+        my_modes += mode + empty_mode;
+        my_max_tot = max(my_max_tot, max(tot, tot_u));
+        my_max_len = max(my_max_len, len8);
+      }
+      const u32 need = (active && len8 > 8u) ? len8 - 8u : 0u;
+      const u32 n0 = rdlane(need, 0), n1 = rdlane(need, 16), n2 = rdlane(need, 32), n3 = rdlane(need, 48);
+      const u32 nsum = n0 + n1 + n2 + n3;
+      u32 ovb = 0u;
+      if (nsum != 0u) {
+        if (chunk_left < nsum) {
+          const u32 grab = nsum > kOverChunk ? nsum : kOverChunk;
+          u32 wbase = 0u;
+          if (lane == 0) wbase = atomicAdd(a.ov_count, grab);
+          chunk_at = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
+          chunk_left = grab;
+        }
+        ovb = chunk_at + (grp > 0 ? n0 : 0u) + (grp > 1 ? n1 : 0u) + (grp > 2 ? n2 : 0u);
+        chunk_at += nsum;
+        chunk_left -= nsum;
+      }
+      const bool ov_ok = active && len8 > 8u && (u64)ovb + (len8 - 8u) <= (u64)a.over_cap;
+      u32* over = a.over + ovb;
+      __builtin_amdgcn_wave_barrier();
+      {
+        const u32 npmax = max(max(rdlane(npair, 0), rdlane(npair, 16)), max(rdlane(npair, 32), rdlane(npair, 48)));
+        u32 cnt = 0u;
+        for (u32 q0 = 0u; q0 < npmax; q0 += 16u) {
+          const u32 pi = q0 + (u32)sl;
+          const bool has = pi < npair;
+          u64 w = has ? ((u64)pairs[1][pi] << 32) | (u64)pairs[0][pi] : 0ull;
+          const u32 k = has ? pairs[2][pi] : 0u;
+          while (__builtin_amdgcn_ballot_w64(w != 0ull) != 0ull) {
+            const bool nzb = w != 0ull;
+            const u32 m = (u32)(__builtin_amdgcn_ballot_w64(nzb) >> gsh) & 0xffffu;
+            const u32 pos = cnt + (u32)__builtin_popcount(m & ltm);
+            const u32 b = nzb ? (u32)__builtin_ctzll(w) : 0u;
+            w &= w - 1ull;
+            const u32 en = (k * 64u + b) << 8;
+            if (nzb) {
+              if (pos < 8u) slots[pl * 8 + (int)pos] = en;
+              else if (ov_ok) over[pos - 8u] = en;
+            }
+            cnt += (u32)__builtin_popcount(m);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (u32 p = max(len, 8u) + (u32)sl; p < len8; p += 16)   // padding of the overflow part
+        if (ov_ok) over[p - 8u] = a.zoff;
+      if (active && sl == 0) {
+        outs[0][pl] = hc ? tot_u : tot;
+        outs[1][pl] = hc ? tot : tot_u;
+        outs[2][pl] = hc ? inc_u : inc;
+        outs[3][pl] = hc ? inc : inc_u;
+        outs[4][pl] = len8 | mode | ((len8 - len) << 28);
+        outs[5][pl] = ovb;
+        outs[6][pl] = hc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- per path: both halves together -> observed score, reported counts ----
+    if (base + lane < a.count) {
+      const i64 i = base + lane;
+      const u32 tot0 = outs[0][lane], tot1 = outs[1][lane];
+      // (+) half: case_pos = inc0, ctrl_neg = tot0 - inc0; (-) half: ctrl_pos = inc1, case_neg = tot1 - inc1 (methods.h:182-185)
+      const u32 case_pos = outs[2][lane], ctrl_neg = tot0 - case_pos;
+      const u32 ctrl_pos = outs[3][lane], case_neg = tot1 - ctrl_pos;
+      const double score = a.dvt[(size_t)sp_diag_offset(tot0) + case_pos] + a.dvt[(size_t)sp_diag_offset(tot1) + case_neg];
+      a.tot[2 * i] = tot0;
+      a.tot[2 * i + 1] = tot1;
+      a.cases[i] = case_pos + case_neg;        // methods.h:256-257
+      a.ctrls[i] = ctrl_pos + ctrl_neg;
+      a.rowz[i] = meta[1][lane];
+      a.key[i] = ie_score_key(score);
+    }
+    // ---- per virtual row (two per path): list info and slot, coalesced; the half that did not change has the empty list ----
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int v = j * 64 + lane, pv = v >> 1;
+      if (base + pv < a.count) {
+        const i64 dd = base * 2 + v;
+        const bool ch = outs[6][pv] == (u32)(v & 1);
+        a.linfo[dd] = ch ? outs[4][pv] : empty_linfo;
+        a.lover[dd] = ch ? outs[5][pv] : 0u;
+        const u32x4 pad = {a.zoff, a.zoff, a.zoff, a.zoff};
+        u32x4* dst = (u32x4*)(a.slot + (u64)dd * 8u);
+        dst[0] = ch ? ((const u32x4*)slots)[pv * 2] : pad;
+        dst[1] = ch ? ((const u32x4*)slots)[pv * 2 + 1] : pad;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (my_max_tot) atomicMax(a.max_tot, my_max_tot);
+  if (my_bad) *a.bad = 1u;
+  if (my_modes) atomicAdd(a.bad + 1, my_modes);
+  if (my_max_len > 8u) atomicMax(a.max_tot + 5, my_max_len);
+}
+
 hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {
   if (a.count == 0) return hipSuccess;
   static const bool v1 = std::getenv("GCRE_STATS_V1") != nullptr;   // the per-path form (cross-check)
@@ -2004,6 +2285,20 @@ hipError_t launch_stats_ie(const StatsArgs& a, int method, hipStream_t stream) {
     else if (nl == 3) hipLaunchKernelGGL((k_stats_ie2<3>), grid, block, 0, stream, a);
     else if (nl == 4) hipLaunchKernelGGL((k_stats_ie2<4>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_stats_ie2<5>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
+  // the signed method with one-sided reduced rows: one round per path (k_stats_ie2h); GCRE_STATS_BOTH_HALVES=1: k_stats_ie2s
+  static const bool both_halves = std::getenv("GCRE_STATS_BOTH_HALVES") != nullptr;
+  if (method == 2 && !v1 && !both_halves && a.Wp <= 160 && a.lz_off) {
+    const i64 nb = (a.count + 63) / 64;
+    const i64 blocks = (nb + 3) / 4;
+    const dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), block(256);
+    const int nl = (a.Wp + 31) / 32;
+    if (nl <= 1) hipLaunchKernelGGL((k_stats_ie2h<1>), grid, block, 0, stream, a);
+    else if (nl == 2) hipLaunchKernelGGL((k_stats_ie2h<2>), grid, block, 0, stream, a);
+    else if (nl == 3) hipLaunchKernelGGL((k_stats_ie2h<3>), grid, block, 0, stream, a);
+    else if (nl == 4) hipLaunchKernelGGL((k_stats_ie2h<4>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_stats_ie2h<5>), grid, block, 0, stream, a);
     return hipGetLastError();
   }
   if (method == 2 && !v1 && a.Wp <= 160) {

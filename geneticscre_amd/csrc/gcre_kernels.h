@@ -228,6 +228,9 @@ struct StatsArgs {
   uint32_t over_cap;           // entries `over` can hold; ov_count beyond it means: grow and run again
   uint32_t* ov_count;          // entries reserved in `over` so far
   uint32_t zoff;
+  // k_stats_ie2h (method 2): CSR offsets of the reduced operand's bit lists (two per row), set only when every row of it
+  // has an empty half
+  const uint64_t* lz_off;
   int64_t first;
   int64_t count;
   int S;
