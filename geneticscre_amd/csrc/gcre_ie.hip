@@ -2001,8 +2001,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? G
 // k_stats_ie2s except the (unused) overflow offset of an empty list.  a.lz_off: the CSR offsets of the reduced rows' bit
 // lists (two lists per row): list 2 r + 1 empty <=> the (-) half of row r is.
 // ------------------------------------------------------------------------------------------------
+#ifndef GCRE_STATS2H_WAVES
+#define GCRE_STATS2H_WAVES 4   // 128 VGPRs, 5 spilled: 7.0 ms per pass on configs[2] geometry against 7.7 at three waves (134, none)
+#endif
 template <int NL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? 3 : 2))) void k_stats_ie2h(const StatsArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? GCRE_STATS2H_WAVES : 2))) void k_stats_ie2h(const StatsArgs a) {
   typedef u64 __attribute__((ext_vector_type(2))) u64x2;
   constexpr u32 kNoRange = 0xffffffffu;
   constexpr u32 kOverChunk = 2048;
