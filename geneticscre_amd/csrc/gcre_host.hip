@@ -1412,61 +1412,6 @@ int run_join(gcre_ctx* c, const JoinPlan& jp, gcre_result* out, JoinMode mode = 
   const gcre_uids& u = *jp.u;
 
   // ---- the checks of JoinExec::join, join_base.cpp:196-200 ----
-
-  // ---- the checks of JoinExec::join, join_base.cpp:196-200 ----
-  if (mode == kFull && std::getenv("GCRE_DUMP_P0")) {   // (diagnostics: what this join finds in paths0 and its recipe)
-    (void)hipDeviceSynchronize();
-    auto fnv = [&](const void* d, size_t bytes) -> unsigned long long {
-      std::vector<unsigned char> h(bytes);
-      if (bytes && hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0ull;
-      unsigned long long x = 1469598103934665603ull;
-      for (unsigned char b : h) { x ^= b; x *= 1099511628211ull; }
-      return x;
-    };
-    const gcre_pathset* p0 = jp.p0;
-    const size_t nr = (size_t)p0->nrows, M = (size_t)c->g.method;
-    std::fprintf(stderr, "[dump dev %d] p0 id %llu rows %zu: rows %016llx", c->device, (unsigned long long)p0->id, nr,
-                 fnv(p0->d_rows, nr * M * (size_t)c->g.S * 8));
-    if (p0->rec && p0->rec->valid) {
-      const gcre_recipe* r = p0->rec;
-      std::fprintf(stderr, " rec row0 %016llx rowz %016llx linfo %016llx lover %016llx tot %016llx slot %016llx max_len %u", fnv(r->row0.p, nr * 4),
-                   fnv(r->rowz.p, nr * 4), fnv(r->linfo.p, nr * M * 4), fnv(r->lover.p, nr * M * 4), fnv(r->tot.p, nr * M * 4),
-                   fnv(r->slot.p, nr * M * 32), r->max_len);
-    }
-    if (p0->rec && p0->rec->valid) {   // the lists as the kernels resolve them: slot entries, then the overflow part
-      const gcre_recipe* r = p0->rec;
-      const size_t nl = nr * M;
-      std::vector<uint32_t> linfo(nl), lover(nl), slot(nl * 8);
-      (void)hipMemcpy(linfo.data(), r->linfo.p, nl * 4, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(lover.data(), r->lover.p, nl * 4, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(slot.data(), r->slot.p, nl * 32, hipMemcpyDeviceToHost);
-      size_t need = 0;
-      for (size_t d = 0; d < nl; d++) {
-        const uint32_t len8 = linfo[d] & 0x0ffffff8u;
-        if (len8 > 8) need = std::max(need, (size_t)lover[d] + (len8 - 8));
-      }
-      std::vector<uint32_t> over(std::min(need, r->over.cap));
-      if (!over.empty()) (void)hipMemcpy(over.data(), r->over.p, over.size() * 4, hipMemcpyDeviceToHost);
-      unsigned long long x = 1469598103934665603ull;
-      size_t longl = 0, beyond = 0;
-      for (size_t d = 0; d < nl; d++) {
-        const uint32_t len8 = linfo[d] & 0x0ffffff8u;
-        std::vector<uint32_t> e(slot.begin() + (long)d * 8, slot.begin() + (long)d * 8 + 8);
-        if (len8 > 8) {
-          longl++;
-          for (uint32_t k = 0; k < len8 - 8; k++) {
-            const size_t at = (size_t)lover[d] + k;
-            if (at < over.size()) e.push_back(over[at]); else beyond++;
-          }
-        }
-        std::sort(e.begin(), e.end());
-        for (uint32_t v : e) { x ^= v; x *= 1099511628211ull; }
-      }
-      std::fprintf(stderr, " lists %016llx (long %zu, beyond %zu, over used %zu of cap %zu)", x, longl, beyond, need, r->over.cap);
-    }
-    std::fprintf(stderr, " max_bits %u known %d planes_valid %d [%lld,%lld) groups %d\n", p0->max_bits, (int)p0->max_known, (int)p0->planes_valid,
-                 (long long)p0->planes_lo, (long long)p0->planes_hi, p0->plane_groups);
-  }
   if (u.n_uids != jp.p0->nrows) return fail(c, GCRE_ERR_ASSERT, "assertion: uids.size() != paths0.size");
   if (u.max_loc >= jp.p1->nrows) return fail(c, GCRE_ERR_RANGE, "assertion: uid location out of range");
   const int64_t P = u.total;
