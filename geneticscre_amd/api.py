@@ -719,9 +719,15 @@ class ResidentPlan:
         self._pivot: Dict[tuple, DeviceUids] = {}
         # off by default: measured -- the level-4 shard gains 3 %, keeping all of level 2's planes costs more
         self.pivot_shards = os.environ.get("GCRE_PIVOT_SHARDS", "0") == "1"
-        # GCRE_AHEAD=1: every join's inspector runs beside the permutation kernel of the join before it (off by default: it
-        # does not pay; the library honours the same variable)
-        self.ahead = os.environ.get("GCRE_AHEAD", "0") == "1"
+        # Inspect- and launch-ahead (gcre_join_ahead): the later joins of a pass are inspected and launched while the first one's
+        # results are collected.  Worth 5-8 % on BASELINE configs[1] (per-join host gaps), 0.5 % on configs[2], nothing or less on
+        # configs[3] (long joins: inspector and permutation kernel each fill the GPU); it keeps every chunk's inspection for the
+        # length of the pass (~130 B per joined path).  Default: plans of up to 64 M joined paths and 10^12 scores per pass.
+        # GCRE_AHEAD=1 / 0: always / never (the library honours the same variable).
+        env_ahead = os.environ.get("GCRE_AHEAD", "")
+        total_paths = sum(int(self.uids[k].total_paths) for k in self.names)
+        self.ahead = env_ahead == "1" or (env_ahead == "" and total_paths <= 64_000_000 and
+                                          total_paths * max(int(problem.iterations), 1) <= 10 ** 12)
         if "4" in self.uids:    # level 2 put the added gene into the (-) half of paths2[loc] when the relation is negative
             self._reduced_args["4"] = (parsed1, np.asarray(lv.data_inds["3"], np.int64) | (rel_neg.astype(np.int64) << 31))
             self.uids["4"].set_reduced(*self._reduced_args["4"])

@@ -314,10 +314,11 @@ struct gcre_ctx {
   uint32_t* d_max_tot_b = nullptr;      // the flag block of ahead inspections (the null kernel in flight owns d_max_tot)
   std::vector<JoinPlan>* ahead = nullptr;   // the registered later joins of the sequence, consumed by the next join call
   bool ahead_closed = false;            // a join that cannot run ahead was offered: nothing behind it is registered either
-  bool ahead_on = false;                // GCRE_AHEAD=1 turns gcre_join_ahead on.  Off by default: measured on configs[2], a pass takes
-                                        // 31.5 ms with it and 31.4 without -- the next level's inspector and this level's permutation
-                                        // kernel each fill the GPU, so running them side by side only trades the host-side gaps for
-                                        // contention (26.1 + 9.9 ms of kernel time inside 31.3 ms instead of 23.0 + 6.0)
+  bool ahead_on = true;                 // GCRE_AHEAD=0 turns gcre_join_ahead into a no-op.  The caller decides which joins to register:
+                                        // measured, the chain is worth 8 % on configs[1] (host gaps between small joins) and
+                                        // 0.5 % on configs[2] -- there the next level's inspector and this level's permutation
+                                        // kernel each fill the GPU (26.1 + 9.9 ms of kernel time inside 31.1 ms instead of
+                                        // 23.0 + 6.0 one after the other)
   SelectState h_sel{};               // where the digit passes' state lands (outlives any one chunk: the copy is asynchronous)
   std::string err;
   int last_code = GCRE_OK;

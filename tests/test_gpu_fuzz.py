@@ -32,7 +32,7 @@ KNOBS = {
     "GCRE_PREFETCH_TABLES": ["", "0"],
     "GCRE_SPARSE_WAVES_PER_CU": ["", "", "4", "16"],
     "GCRE_IE_SJT": ["", "1", "64"],
-    "GCRE_AHEAD": ["", "", "1"],                        # inspect-ahead (ResidentPlan passes only; off by default)
+    "GCRE_AHEAD": ["", "0", "1"],                       # inspect- and launch-ahead (ResidentPlan passes only; default: plans up to 64 M paths)
 }
 
 

@@ -24,6 +24,13 @@ def check(got, want, L):
         assert_same_result(got[name], want[lst])
 
 
+@pytest.fixture(autouse=True)
+def _no_chain_unless_asked(monkeypatch):
+    """The replay counts below are those of the cache alone: the launch-ahead chain (on by default for plans of this size)
+    replays the first window's joins too.  The chain's own tests take the variable out again."""
+    monkeypatch.setenv("GCRE_AHEAD", "0")
+
+
 @pytest.mark.parametrize("kernel", ["auto", "ie", "sparse", "dense"])
 @pytest.mark.parametrize("method", ["method1", "method2"])
 def test_later_windows_start_at_the_null_kernel(method, kernel, monkeypatch):
@@ -194,11 +201,11 @@ def test_kept_inspections_without_permutations_and_with_a_sentinel(method):
 @pytest.mark.parametrize("method", ["method1", "method2"])
 @pytest.mark.parametrize("kernel,chunk,window", [("", "", ""), ("ie", "900", ""), ("ie", "", "1"), ("sparse", "", ""), ("dense", "", "")])
 def test_inspect_ahead_gives_the_same_results(method, kernel, chunk, window, monkeypatch):
-    """GCRE_AHEAD=1 (gcre_join_ahead): every join's inspector runs on a stream of its own beside the permutation kernel of the
-    join before it, into the next join's inspection cache; the next join starts at its null kernel.  Off by default (it does not
-    pay: DESIGN.md), exact like everything else: single and several chunks per join, two permutation windows, the kernel forms
-    that do not run the inclusion-exclusion inspector, a sharded pass."""
-    monkeypatch.setenv("GCRE_AHEAD", "1")
+    """gcre_join_ahead: every join's inspector runs on a stream of its own beside the permutation kernel of the join before it,
+    into the next join's inspection cache; the next join starts at its null kernel.  The default for plans of up to 64 M joined
+    paths (GCRE_AHEAD=0 turns it off, =1 on for any size), exact like everything else: single and several chunks per join, two
+    permutation windows, the kernel forms that do not run the inclusion-exclusion inspector, a sharded pass."""
+    monkeypatch.delenv("GCRE_AHEAD", raising=False)
     for k, v in (("GCRE_NULL_KERNEL", kernel), ("GCRE_CHUNK_PATHS", chunk), ("GCRE_WINDOW_TILES", window)):
         if v:
             monkeypatch.setenv(k, v)
@@ -217,5 +224,21 @@ def test_inspect_ahead_gives_the_same_results(method, kernel, chunk, window, mon
         for name, lvl in (("1b", 1), ("4", 4), ("5", 5)):
             null = np.maximum.reduce([q[name].null for q in parts])
             assert np.array_equal(null.view(np.uint32), want[f"lst{lvl}"].null.view(np.uint32)), (name,)
+    finally:
+        plan.close()
+
+
+def test_inspect_ahead_switch(monkeypatch):
+    """GCRE_AHEAD=0: no chain is registered, every join runs whole -- same results."""
+    monkeypatch.setenv("GCRE_AHEAD", "0")
+    p = make_problem(90, 330, 61, 70, 300, 4, method="method1", top_k=13, seed=78)
+    want = oracle.process_paths(p, order="canonical", nthreads=4)
+    plan = api.ResidentPlan(p)
+    try:
+        assert not plan.ahead
+        got = plan.run()
+        for name, lvl in (("1b", 1), ("2", 2), ("3", 3), ("4", 4)):
+            assert_same_result(got[name], want[f"lst{lvl}"])
+        assert plan.last_profile["inspect_replays"] == 0
     finally:
         plan.close()
